@@ -1,0 +1,878 @@
+/*
+ * rmpc_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ * See rmpc_oracle.h for scope, the "parity unpinned" statement and the list
+ * of reference files restated.  Dense, runtime-dimensioned, deliberately plain.
+ */
+#include "rmpc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NVM ORC_NV_MAX
+#define NXM ORC_NX_MAX
+#define NWM ORC_NW_MAX
+#define MRM ORC_MR_MAX
+
+int orc_desc_size(void) { return (int)sizeof(orc_desc); }
+
+static int nvar_of(const orc_desc *d) { return d->nx + d->ns + d->nu; }
+
+/* ------------------------------------------------------------------ */
+/* small dense helpers                                                  */
+/* ------------------------------------------------------------------ */
+static void mat3_mul(const double *a, const double *b, double *c) {
+  double r[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += a[3 * i + k] * b[3 * k + j];
+      r[3 * i + j] = s;
+    }
+  memcpy(c, r, sizeof r);
+}
+static void mat3_vec(const double *a, const double *v, double *o) {
+  double r[3];
+  for (int i = 0; i < 3; i++) r[i] = a[3 * i] * v[0] + a[3 * i + 1] * v[1] + a[3 * i + 2] * v[2];
+  o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
+}
+/* Rodrigues rotation about unit axis k by angle th */
+static void rot_axis(const double *k, double th, double *R) {
+  double c = cos(th), s = sin(th), v = 1.0 - c;
+  R[0] = c + k[0] * k[0] * v;        R[1] = k[0] * k[1] * v - k[2] * s; R[2] = k[0] * k[2] * v + k[1] * s;
+  R[3] = k[1] * k[0] * v + k[2] * s; R[4] = c + k[1] * k[1] * v;        R[5] = k[1] * k[2] * v - k[0] * s;
+  R[6] = k[2] * k[0] * v - k[1] * s; R[7] = k[2] * k[1] * v + k[0] * s; R[8] = c + k[2] * k[2] * v;
+}
+
+/* ------------------------------------------------------------------ */
+/* forward kinematics (restates the .fk(q, root, link, positionOnly=True)
+ * call sites: mpcBase.py:89-94, goal_reaching.py:22-27,
+ * LinearConstraints.py:30-35, SelfCollisionAvoidanceConstraints.py:23-24) */
+/* ------------------------------------------------------------------ */
+int orc_fk(const orc_desc *d, const double *q, int frame, double *pos, double *Jp) {
+  const int n = d->n;
+  if (frame < 0 || frame >= d->n_joints) return -1;
+  for (int i = 0; i < 3 * n; i++) Jp[i] = 0.0;
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+  if (d->robot == ORC_ROBOT_DIFFDRIVE) {
+    /* base pose (x, y, theta) prefixes a chain of fixed joints (fk.n() == 0) */
+    for (int j = 0; j <= frame; j++) {
+      if (d->joint_type[j] != ORC_JOINT_FIXED) return -2;
+      double t[3];
+      mat3_vec(R, d->joint_xyz[j], t);
+      o[0] += t[0]; o[1] += t[1]; o[2] += t[2];
+      mat3_mul(R, d->joint_rot[j], R);
+    }
+    double c = cos(q[2]), s = sin(q[2]);
+    pos[0] = q[0] + c * o[0] - s * o[1];
+    pos[1] = q[1] + s * o[0] + c * o[1];
+    pos[2] = o[2];
+    Jp[0 * n + 0] = 1.0;
+    Jp[1 * n + 1] = 1.0;
+    Jp[0 * n + 2] = -s * o[0] - c * o[1];
+    Jp[1 * n + 2] = c * o[0] - s * o[1];
+    return 0;
+  }
+  double oj[ORC_MAX_JOINTS][3], aj[ORC_MAX_JOINTS][3];
+  for (int j = 0; j <= frame; j++) {
+    double t[3];
+    mat3_vec(R, d->joint_xyz[j], t);
+    o[0] += t[0]; o[1] += t[1]; o[2] += t[2];
+    mat3_mul(R, d->joint_rot[j], R);
+    mat3_vec(R, d->joint_axis[j], aj[j]);
+    oj[j][0] = o[0]; oj[j][1] = o[1]; oj[j][2] = o[2];
+    if (d->joint_type[j] == ORC_JOINT_REVOLUTE) {
+      double Rq[9];
+      rot_axis(d->joint_axis[j], q[d->joint_dof[j]], Rq);
+      mat3_mul(R, Rq, R);
+    } else if (d->joint_type[j] == ORC_JOINT_PRISMATIC) {
+      double qq = q[d->joint_dof[j]];
+      o[0] += aj[j][0] * qq; o[1] += aj[j][1] * qq; o[2] += aj[j][2] * qq;
+    }
+  }
+  pos[0] = o[0]; pos[1] = o[1]; pos[2] = o[2];
+  for (int j = 0; j <= frame; j++) {
+    int dof = d->joint_dof[j];
+    if (d->joint_type[j] == ORC_JOINT_REVOLUTE) {
+      double r[3] = {o[0] - oj[j][0], o[1] - oj[j][1], o[2] - oj[j][2]};
+      Jp[0 * n + dof] = aj[j][1] * r[2] - aj[j][2] * r[1];
+      Jp[1 * n + dof] = aj[j][2] * r[0] - aj[j][0] * r[2];
+      Jp[2 * n + dof] = aj[j][0] * r[1] - aj[j][1] * r[0];
+    } else if (d->joint_type[j] == ORC_JOINT_PRISMATIC) {
+      Jp[0 * n + dof] = aj[j][0];
+      Jp[1 * n + dof] = aj[j][1];
+      Jp[2 * n + dof] = aj[j][2];
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* dynamics: continuous model + ERK2 (explicit midpoint) x 5 nodes      */
+/* mpcModel.py:65-69, diff_drive_mpc_model.py:24-41, mpcModel.py:118-120 */
+/* ------------------------------------------------------------------ */
+static void cont_dyn(const orc_desc *d, const double *x, const double *u,
+                     double *xd, double *fx, double *fu) {
+  const int nx = d->nx, nu = d->nu, n = d->n;
+  if (fx) memset(fx, 0, sizeof(double) * nx * nx);
+  if (fu) memset(fu, 0, sizeof(double) * nx * nu);
+  if (d->robot == ORC_ROBOT_CHAIN) {
+    for (int i = 0; i < n; i++) {
+      xd[i] = x[n + i];
+      xd[n + i] = u[i];
+      if (fx) fx[i * nx + n + i] = 1.0;
+      if (fu) fu[(n + i) * nu + i] = 1.0;
+    }
+  } else {
+    double th = x[2], v = x[6], w = x[7];
+    double c = cos(th), s = sin(th);
+    xd[0] = c * v; xd[1] = s * v; xd[2] = w;
+    xd[3] = 0; xd[4] = 0; xd[5] = 0;
+    xd[6] = u[0]; xd[7] = u[1];
+    if (fx) {
+      fx[0 * nx + 2] = -s * v; fx[0 * nx + 6] = c;
+      fx[1 * nx + 2] = c * v;  fx[1 * nx + 6] = s;
+      fx[2 * nx + 7] = 1.0;
+    }
+    if (fu) { fu[6 * nu + 0] = 1.0; fu[7 * nu + 1] = 1.0; }
+  }
+}
+
+#define ORC_ERK_NODES 5
+/* A: nx x nx, Bu: nx x nu (w.r.t. the control only; slack never enters) */
+static void disc_dyn(const orc_desc *d, const double *x0, const double *u,
+                     double *xn, double *A, double *Bu) {
+  const int nx = d->nx, nu = d->nu;
+  const double h = d->dt / ORC_ERK_NODES;
+  double x[NXM];
+  memcpy(x, x0, sizeof(double) * nx);
+  if (A) {
+    memset(A, 0, sizeof(double) * nx * nx);
+    for (int i = 0; i < nx; i++) A[i * nx + i] = 1.0;
+    memset(Bu, 0, sizeof(double) * nx * nu);
+  }
+  for (int it = 0; it < ORC_ERK_NODES; it++) {
+    double k1[NXM], k2[NXM], xm[NXM];
+    double fx1[NXM * NXM], fu1[NXM * NWM], fx2[NXM * NXM], fu2[NXM * NWM];
+    cont_dyn(d, x, u, k1, A ? fx1 : 0, A ? fu1 : 0);
+    for (int i = 0; i < nx; i++) xm[i] = x[i] + 0.5 * h * k1[i];
+    cont_dyn(d, xm, u, k2, A ? fx2 : 0, A ? fu2 : 0);
+    if (A) {
+      /* As = I + h fx2 (I + h/2 fx1);  Bs = h (fx2 (h/2 fu1) + fu2) */
+      double M[NXM * NXM], As[NXM * NXM], Bs[NXM * NWM], T[NXM * NXM], TB[NXM * NWM];
+      for (int i = 0; i < nx; i++)
+        for (int j = 0; j < nx; j++) M[i * nx + j] = (i == j ? 1.0 : 0.0) + 0.5 * h * fx1[i * nx + j];
+      for (int i = 0; i < nx; i++)
+        for (int j = 0; j < nx; j++) {
+          double s = 0;
+          for (int k = 0; k < nx; k++) s += fx2[i * nx + k] * M[k * nx + j];
+          As[i * nx + j] = (i == j ? 1.0 : 0.0) + h * s;
+        }
+      for (int i = 0; i < nx; i++)
+        for (int j = 0; j < nu; j++) {
+          double s = 0;
+          for (int k = 0; k < nx; k++) s += fx2[i * nx + k] * (0.5 * h * fu1[k * nu + j]);
+          Bs[i * nu + j] = h * (s + fu2[i * nu + j]);
+        }
+      for (int i = 0; i < nx; i++)
+        for (int j = 0; j < nx; j++) {
+          double s = 0;
+          for (int k = 0; k < nx; k++) s += As[i * nx + k] * A[k * nx + j];
+          T[i * nx + j] = s;
+        }
+      for (int i = 0; i < nx; i++)
+        for (int j = 0; j < nu; j++) {
+          double s = 0;
+          for (int k = 0; k < nx; k++) s += As[i * nx + k] * Bu[k * nu + j];
+          TB[i * nu + j] = s + Bs[i * nu + j];
+        }
+      memcpy(A, T, sizeof(double) * nx * nx);
+      memcpy(Bu, TB, sizeof(double) * nx * nu);
+    }
+    for (int i = 0; i < nx; i++) x[i] += h * k2[i];
+  }
+  memcpy(xn, x, sizeof(double) * nx);
+}
+
+int orc_dynamics(const orc_desc *d, const double *x, const double *u, double *xnext) {
+  disc_dyn(d, x, u, xnext, 0, 0);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* rows                                                                 */
+/* ------------------------------------------------------------------ */
+static int module_rows(const orc_desc *d, int kind) {
+  switch (kind) {
+    case ORC_MOD_RADIAL: return d->nobst * d->n_links;          /* RadialConstraints.py:9 */
+    case ORC_MOD_LINEAR: return d->nobst * d->n_links;          /* LinearConstraints.py:13 */
+    case ORC_MOD_SELFCOLLISION: return d->n_pairs;              /* SelfCollision...py:13 */
+    case ORC_MOD_JOINTLIMIT: return 2 * d->n;                   /* JointLimitConstraints.py:10 */
+    case ORC_MOD_VELLIMIT: return 4;                            /* VelLimitConstraints.py:28-31 (4 rows; _n_ineq=2 is a bug) */
+    case ORC_MOD_INPUTLIMIT: return 2 * d->nu;                  /* InputLimitConstraints.py:7 */
+  }
+  return -1;
+}
+
+int orc_num_rows(const orc_desc *d, int *nh_out, int *m_out) {
+  int nh = 0;
+  for (int i = 0; i < d->n_modules; i++) {
+    int r = module_rows(d, d->module_kind[i]);
+    if (r < 0) return -1;
+    nh += r;
+  }
+  int m = nh;
+  const int nv = nvar_of(d);
+  for (int j = 0; j < nv; j++) {
+    if (isfinite(d->lb[j])) m++;
+    if (isfinite(d->ub[j])) m++;
+  }
+  if (nh > ORC_NH_MAX || m > MRM) return -2;
+  if (nh_out) *nh_out = nh;
+  if (m_out) *m_out = m;
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* stage evaluation                                                     */
+/* ------------------------------------------------------------------ */
+#define ORC_EVAL_BAD_AVOID (-100) /* an inverse-barrier row has h <= 0 */
+
+int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
+                   int want, double *f_out, double *gf, double *H, double *g,
+                   double *Jg, double *xnext, double *A, double *Bm) {
+  const int n = d->n, nx = d->nx, ns = d->ns, nu = d->nu, nv = nx + ns + nu, nw = ns + nu;
+  const double *q = z;
+  const double *u = z + nx + ns;
+  const double s = ns ? z[nx] : 0.0;
+  double f = 0.0;
+  int bad = 0;
+  if (want) {
+    memset(gf, 0, sizeof(double) * nv);
+    memset(H, 0, sizeof(double) * nv * nv);
+  }
+  /* --- kinematics cache --- */
+  double fpos[ORC_MAX_JOINTS][3], fJ[ORC_MAX_JOINTS][3 * 8];
+  int fdone[ORC_MAX_JOINTS] = {0};
+#define NEED_FK(fr)                                         \
+  do {                                                      \
+    if (!fdone[fr]) {                                       \
+      if (orc_fk(d, q, fr, fpos[fr], fJ[fr]) != 0) return -1; \
+      fdone[fr] = 1;                                        \
+    }                                                       \
+  } while (0)
+
+  /* --- GoalReaching (goal_reaching.py:19-33) --- */
+  if (d->has_goal) {
+    const double *goal = p + d->off_goal, *w = p + d->off_wgoal;
+    NEED_FK(d->end_frame);
+    const double *pe = fpos[d->end_frame], *J = fJ[d->end_frame];
+    double e[3];
+    for (int i = 0; i < 3; i++) { e[i] = pe[i] - goal[i]; f += w[i] * e[i] * e[i]; }
+    if (want) {
+      for (int a = 0; a < n; a++) {
+        double ga = 0;
+        for (int i = 0; i < 3; i++) ga += 2.0 * w[i] * e[i] * J[i * n + a];
+        gf[a] += ga;
+        for (int b = 0; b < n; b++) {
+          double hab = 0;
+          for (int i = 0; i < 3; i++) hab += 2.0 * w[i] * J[i * n + a] * J[i * n + b];
+          H[a * nv + b] += hab;
+        }
+      }
+    }
+  }
+  /* --- control effort + slack penalty (ObjectiveManager.py:28-42) --- */
+  {
+    const double *wu = p + d->off_wu;
+    for (int j = 0; j < nu; j++) {
+      f += wu[j] * u[j] * u[j];
+      if (want) {
+        gf[nx + ns + j] += 2.0 * wu[j] * u[j];
+        H[(nx + ns + j) * nv + nx + ns + j] += 2.0 * wu[j];
+      }
+    }
+    if (ns) {
+      double ws = p[d->off_ws];
+      f += ws * s * s;
+      if (want) { gf[nx] += 2.0 * ws * s; H[nx * nv + nx] += 2.0 * ws; }
+    }
+  }
+  /* --- inequality modules, YAML order (InequalityManager.py:25-33) --- */
+  int row = 0;
+  if (want) memset(Jg, 0, sizeof(double) * MRM * nv);
+  for (int mi = 0; mi < d->n_modules; mi++) {
+    const int kind = d->module_kind[mi];
+    const int row0 = row;
+    if (kind == ORC_MOD_RADIAL) {
+      /* mpcBase.py:82-101: links outer, obstacles inner */
+      const double rb = p[d->off_r_body];
+      for (int l = 0; l < d->n_links; l++) {
+        int fr = d->link_frame[l];
+        NEED_FK(fr);
+        for (int i = 0; i < d->nobst; i++) {
+          const double *ob = p + d->off_obst + 4 * i;
+          double dv[3] = {fpos[fr][0] - ob[0], fpos[fr][1] - ob[1], fpos[fr][2] - ob[2]};
+          double dist = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+          g[row] = dist - ob[3] - rb;
+          if (want)
+            for (int a = 0; a < n; a++)
+              Jg[row * nv + a] = (dv[0] * fJ[fr][0 * n + a] + dv[1] * fJ[fr][1 * n + a] + dv[2] * fJ[fr][2 * n + a]) / dist;
+          row++;
+        }
+      }
+    } else if (kind == ORC_MOD_LINEAR) {
+      /* LinearConstraints.py:25-40, utils.py:48-52 */
+      const double rb = p[d->off_r_body];
+      for (int l = 0; l < d->n_links; l++) {
+        int fr = d->link_frame[l];
+        NEED_FK(fr);
+        for (int i = 0; i < d->nobst; i++) {
+          const double *pl = p + d->off_lin + 4 * i;
+          double nn = sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
+          double sd = pl[0] * fpos[fr][0] + pl[1] * fpos[fr][1] + pl[2] * fpos[fr][2] + pl[3];
+          double sg = sd < 0 ? -1.0 : 1.0;
+          g[row] = fabs(sd) / nn - rb;
+          if (want)
+            for (int a = 0; a < n; a++)
+              Jg[row * nv + a] = sg * (pl[0] * fJ[fr][0 * n + a] + pl[1] * fJ[fr][1 * n + a] + pl[2] * fJ[fr][2 * n + a]) / nn;
+          row++;
+        }
+      }
+    } else if (kind == ORC_MOD_SELFCOLLISION) {
+      /* SelfCollisionAvoidanceConstraints.py:19-27 */
+      const double rb = p[d->off_r_body];
+      for (int pi = 0; pi < d->n_pairs; pi++) {
+        int fa = d->pair_frame[pi][0], fb = d->pair_frame[pi][1];
+        NEED_FK(fa);
+        NEED_FK(fb);
+        double dv[3] = {fpos[fa][0] - fpos[fb][0], fpos[fa][1] - fpos[fb][1], fpos[fa][2] - fpos[fb][2]};
+        double dist = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+        g[row] = dist - 2.0 * rb;
+        if (want)
+          for (int a = 0; a < n; a++) {
+            double s3 = 0;
+            for (int i = 0; i < 3; i++) s3 += dv[i] * (fJ[fa][i * n + a] - fJ[fb][i * n + a]);
+            Jg[row * nv + a] = s3 / dist;
+          }
+        row++;
+      }
+    } else if (kind == ORC_MOD_JOINTLIMIT) {
+      /* JointLimitConstraints.py:21-31 */
+      const double *lo = p + d->off_lower, *hi = p + d->off_upper;
+      for (int j = 0; j < n; j++) {
+        g[row] = q[j] - lo[j];
+        if (want) Jg[row * nv + j] = 1.0;
+        row++;
+        g[row] = hi[j] - q[j];
+        if (want) Jg[row * nv + j] = -1.0;
+        row++;
+      }
+    } else if (kind == ORC_MOD_VELLIMIT) {
+      /* VelLimitConstraints.py:20-31: vel = z[n:nx][-2:] */
+      const double *lo = p + d->off_lower_vel, *hi = p + d->off_upper_vel;
+      for (int j = 0; j < 2; j++) {
+        int idx = nx - 2 + j;
+        g[row] = z[idx] - lo[j];
+        if (want) Jg[row * nv + idx] = 1.0;
+        row++;
+        g[row] = hi[j] - z[idx];
+        if (want) Jg[row * nv + idx] = -1.0;
+        row++;
+      }
+    } else if (kind == ORC_MOD_INPUTLIMIT) {
+      /* InputLimitConstraints.py:19-29 */
+      const double *lo = p + d->off_lower_u, *hi = p + d->off_upper_u;
+      for (int j = 0; j < nu; j++) {
+        int idx = nx + ns + j;
+        g[row] = u[j] - lo[j];
+        if (want) Jg[row * nv + idx] = 1.0;
+        row++;
+        g[row] = hi[j] - u[j];
+        if (want) Jg[row * nv + idx] = -1.0;
+        row++;
+      }
+    } else {
+      return -3;
+    }
+    /* --- ConstraintAvoidance (constraint_avoidance.py:22-31): N * w_i / h_first --- */
+    if (d->has_avoid && row > row0) {
+      double wi = p[d->off_wconstr + mi];
+      if (wi != 0.0) {
+        double c = (double)d->N * wi;
+        double h = g[row0];
+        if (!(h > 0.0)) bad = 1;
+        f += c / h;
+        if (want) {
+          const double *jr = Jg + row0 * nv;
+          double c1 = -c / (h * h), c2 = 2.0 * c / (h * h * h);
+          for (int a = 0; a < nv; a++) {
+            gf[a] += c1 * jr[a];
+            if (jr[a] != 0.0)
+              for (int b = 0; b < nv; b++) H[a * nv + b] += c2 * jr[a] * jr[b];
+          }
+        }
+      }
+    }
+  }
+  /* slack softening of every general row (intended semantics of
+   * InequalityManager.py:29-32) */
+  if (ns) {
+    for (int r = 0; r < row; r++) {
+      g[r] += s;
+      if (want) Jg[r * nv + nx] = 1.0;
+    }
+  }
+  /* simple bounds lb <= z <= ub (mpcModel.py:91-104) */
+  for (int j = 0; j < nv; j++)
+    if (isfinite(d->lb[j])) {
+      g[row] = z[j] - d->lb[j];
+      if (want) Jg[row * nv + j] = 1.0;
+      row++;
+    }
+  for (int j = 0; j < nv; j++)
+    if (isfinite(d->ub[j])) {
+      g[row] = d->ub[j] - z[j];
+      if (want) Jg[row * nv + j] = -1.0;
+      row++;
+    }
+  /* dynamics */
+  if (xnext) {
+    double Bu[NXM * NWM];
+    disc_dyn(d, z, u, xnext, want ? A : 0, want ? Bu : 0);
+    if (want) {
+      for (int i = 0; i < nx; i++) {
+        for (int j = 0; j < nw; j++) Bm[i * nw + j] = 0.0;
+        for (int j = 0; j < nu; j++) Bm[i * nw + ns + j] = Bu[i * nu + j];
+      }
+    }
+  }
+  *f_out = f;
+  return bad ? ORC_EVAL_BAD_AVOID : row;
+#undef NEED_FK
+}
+
+/* ------------------------------------------------------------------ */
+/* primal-dual interior point with stage-wise Riccati factorisation     */
+/* ------------------------------------------------------------------ */
+#define ORC_TMIN 1e-2      /* slack push at initialisation */
+#define ORC_TAU 0.995      /* fraction to the boundary */
+#define ORC_LS_MAX 25      /* max halvings in the line search */
+#define ORC_ARMIJO 1e-4
+#define ORC_MU_DIVERGED 1e12
+#define ORC_TRACE_W 8
+
+typedef struct {
+  int N, nx, nw, nv, m;
+  double *z, *t, *lam, *nu;
+  double *f, *gf, *H, *g, *Jg, *xn, *A, *Bm;
+  double *Q, *qv, *rc;
+  double *K, *kff, *P, *pv;
+  double *dz, *dtt, *dlam, *nunew;
+  double *zt, *tt, *gt, *xnt;
+} orc_work;
+
+static double *dalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
+
+static int work_alloc(orc_work *w, const orc_desc *d, int m) {
+  const int N = d->N, nx = d->nx, nv = nvar_of(d), nw = d->ns + d->nu;
+  w->N = N; w->nx = nx; w->nw = nw; w->nv = nv; w->m = m;
+  w->z = dalloc((size_t)N * nv); w->t = dalloc((size_t)N * m); w->lam = dalloc((size_t)N * m);
+  w->nu = dalloc((size_t)N * nx);
+  w->f = dalloc(N); w->gf = dalloc((size_t)N * nv); w->H = dalloc((size_t)N * nv * nv);
+  w->g = dalloc((size_t)N * MRM); w->Jg = dalloc((size_t)N * MRM * nv);
+  w->xn = dalloc((size_t)N * nx); w->A = dalloc((size_t)N * nx * nx); w->Bm = dalloc((size_t)N * nx * nw);
+  w->Q = dalloc((size_t)N * nv * nv); w->qv = dalloc((size_t)N * nv); w->rc = dalloc((size_t)N * nx);
+  w->K = dalloc((size_t)N * nw * nx); w->kff = dalloc((size_t)N * nw);
+  w->P = dalloc((size_t)N * nx * nx); w->pv = dalloc((size_t)N * nx);
+  w->dz = dalloc((size_t)N * nv); w->dtt = dalloc((size_t)N * m); w->dlam = dalloc((size_t)N * m);
+  w->nunew = dalloc((size_t)N * nx);
+  w->zt = dalloc((size_t)N * nv); w->tt = dalloc((size_t)N * m); w->gt = dalloc((size_t)N * MRM);
+  w->xnt = dalloc((size_t)N * nx);
+  return 0;
+}
+static void work_free(orc_work *w) {
+  free(w->z); free(w->t); free(w->lam); free(w->nu); free(w->f); free(w->gf); free(w->H);
+  free(w->g); free(w->Jg); free(w->xn); free(w->A); free(w->Bm); free(w->Q); free(w->qv);
+  free(w->rc); free(w->K); free(w->kff); free(w->P); free(w->pv); free(w->dz); free(w->dtt);
+  free(w->dlam); free(w->nunew); free(w->zt); free(w->tt); free(w->gt); free(w->xnt);
+}
+
+/* evaluate every stage with derivatives at w->z; returns 0, or <0 */
+static int eval_all(const orc_desc *d, orc_work *w, const double *params) {
+  const int N = w->N, nv = w->nv, nx = w->nx, nw = w->nw;
+  int rc = 0;
+  for (int k = 0; k < N; k++) {
+    int r = orc_eval_stage(d, w->z + (size_t)k * nv, params + (size_t)k * d->npar, 1, &w->f[k],
+                           w->gf + (size_t)k * nv, w->H + (size_t)k * nv * nv, w->g + (size_t)k * MRM,
+                           w->Jg + (size_t)k * MRM * nv, k < N - 1 ? w->xn + (size_t)k * nx : 0,
+                           w->A + (size_t)k * nx * nx, w->Bm + (size_t)k * nx * nw);
+    if (r == ORC_EVAL_BAD_AVOID) rc = ORC_EVAL_BAD_AVOID;
+    else if (r < 0) return r;
+  }
+  return rc;
+}
+
+/* Cholesky of the nw x nw block, in place (lower). returns 0 ok */
+static int chol(double *M, int n) {
+  for (int j = 0; j < n; j++) {
+    double dg = M[j * n + j];
+    for (int k = 0; k < j; k++) dg -= M[j * n + k] * M[j * n + k];
+    if (!(dg > 0.0)) return -1;
+    dg = sqrt(dg);
+    M[j * n + j] = dg;
+    for (int i = j + 1; i < n; i++) {
+      double s = M[i * n + j];
+      for (int k = 0; k < j; k++) s -= M[i * n + k] * M[j * n + k];
+      M[i * n + j] = s / dg;
+    }
+  }
+  return 0;
+}
+static void chol_solve(const double *L, int n, double *b) {
+  for (int i = 0; i < n; i++) {
+    double s = b[i];
+    for (int k = 0; k < i; k++) s -= L[i * n + k] * b[k];
+    b[i] = s / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = b[i];
+    for (int k = i + 1; k < n; k++) s -= L[k * n + i] * b[k];
+    b[i] = s / L[i * n + i];
+  }
+}
+
+/* Riccati backward + forward on the condensed stage QPs. */
+static int riccati(orc_work *w) {
+  const int N = w->N, nx = w->nx, nw = w->nw, nv = w->nv;
+  double Pn[NXM * NXM], pn[NXM];
+  memset(Pn, 0, sizeof Pn);
+  memset(pn, 0, sizeof pn);
+  for (int k = N - 1; k >= 0; k--) {
+    const double *Q = w->Q + (size_t)k * nv * nv, *qv = w->qv + (size_t)k * nv;
+    double Qxx[NXM * NXM], Qxw[NXM * NWM], Qww[NWM * NWM], qx[NXM], qw[NWM];
+    for (int i = 0; i < nx; i++) {
+      for (int j = 0; j < nx; j++) Qxx[i * nx + j] = Q[i * nv + j];
+      for (int j = 0; j < nw; j++) Qxw[i * nw + j] = Q[i * nv + nx + j];
+      qx[i] = qv[i];
+    }
+    for (int i = 0; i < nw; i++) {
+      for (int j = 0; j < nw; j++) Qww[i * nw + j] = Q[(nx + i) * nv + nx + j];
+      qw[i] = qv[nx + i];
+    }
+    if (k < N - 1) {
+      const double *A = w->A + (size_t)k * nx * nx, *Bm = w->Bm + (size_t)k * nx * nw;
+      const double *rc = w->rc + (size_t)k * nx;
+      double PA[NXM * NXM], PB[NXM * NWM], Pc[NXM];
+      for (int i = 0; i < nx; i++) {
+        for (int j = 0; j < nx; j++) {
+          double s = 0;
+          for (int l = 0; l < nx; l++) s += Pn[i * nx + l] * A[l * nx + j];
+          PA[i * nx + j] = s;
+        }
+        for (int j = 0; j < nw; j++) {
+          double s = 0;
+          for (int l = 0; l < nx; l++) s += Pn[i * nx + l] * Bm[l * nw + j];
+          PB[i * nw + j] = s;
+        }
+        double s = pn[i];
+        for (int l = 0; l < nx; l++) s += Pn[i * nx + l] * rc[l];
+        Pc[i] = s;
+      }
+      for (int i = 0; i < nx; i++) {
+        for (int j = 0; j < nx; j++) {
+          double s = 0;
+          for (int l = 0; l < nx; l++) s += A[l * nx + i] * PA[l * nx + j];
+          Qxx[i * nx + j] += s;
+        }
+        for (int j = 0; j < nw; j++) {
+          double s = 0;
+          for (int l = 0; l < nx; l++) s += A[l * nx + i] * PB[l * nw + j];
+          Qxw[i * nw + j] += s;
+        }
+        double s = 0;
+        for (int l = 0; l < nx; l++) s += A[l * nx + i] * Pc[l];
+        qx[i] += s;
+      }
+      for (int i = 0; i < nw; i++) {
+        for (int j = 0; j < nw; j++) {
+          double s = 0;
+          for (int l = 0; l < nx; l++) s += Bm[l * nw + i] * PB[l * nw + j];
+          Qww[i * nw + j] += s;
+        }
+        double s = 0;
+        for (int l = 0; l < nx; l++) s += Bm[l * nw + i] * Pc[l];
+        qw[i] += s;
+      }
+    }
+    if (chol(Qww, nw) != 0) return -1;
+    double *K = w->K + (size_t)k * nw * nx, *kff = w->kff + (size_t)k * nw;
+    for (int j = 0; j < nx; j++) {
+      double col[NWM];
+      for (int i = 0; i < nw; i++) col[i] = -Qxw[j * nw + i];
+      chol_solve(Qww, nw, col);
+      for (int i = 0; i < nw; i++) K[i * nx + j] = col[i];
+    }
+    for (int i = 0; i < nw; i++) kff[i] = -qw[i];
+    chol_solve(Qww, nw, kff);
+    double *P = w->P + (size_t)k * nx * nx, *pv = w->pv + (size_t)k * nx;
+    for (int i = 0; i < nx; i++) {
+      for (int j = 0; j < nx; j++) {
+        double s = Qxx[i * nx + j];
+        for (int l = 0; l < nw; l++) s += Qxw[i * nw + l] * K[l * nx + j];
+        P[i * nx + j] = s;
+      }
+      double s = qx[i];
+      for (int l = 0; l < nw; l++) s += Qxw[i * nw + l] * kff[l];
+      pv[i] = s;
+    }
+    for (int i = 0; i < nx; i++)
+      for (int j = i + 1; j < nx; j++) {
+        double a = 0.5 * (P[i * nx + j] + P[j * nx + i]);
+        P[i * nx + j] = a;
+        P[j * nx + i] = a;
+      }
+    memcpy(Pn, P, sizeof(double) * nx * nx);
+    memcpy(pn, pv, sizeof(double) * nx);
+  }
+  /* forward */
+  double dx[NXM];
+  memset(dx, 0, sizeof dx);
+  for (int k = 0; k < N; k++) {
+    const double *K = w->K + (size_t)k * nw * nx, *kff = w->kff + (size_t)k * nw;
+    double *dz = w->dz + (size_t)k * nv;
+    for (int i = 0; i < nx; i++) dz[i] = dx[i];
+    for (int i = 0; i < nw; i++) {
+      double s = kff[i];
+      for (int j = 0; j < nx; j++) s += K[i * nx + j] * dx[j];
+      dz[nx + i] = s;
+    }
+    const double *P = w->P + (size_t)k * nx * nx, *pv = w->pv + (size_t)k * nx;
+    for (int i = 0; i < nx; i++) {
+      double s = pv[i];
+      for (int j = 0; j < nx; j++) s += P[i * nx + j] * dx[j];
+      w->nunew[(size_t)k * nx + i] = s;
+    }
+    if (k < N - 1) {
+      const double *A = w->A + (size_t)k * nx * nx, *Bm = w->Bm + (size_t)k * nx * nw;
+      const double *rc = w->rc + (size_t)k * nx;
+      double dxn[NXM];
+      for (int i = 0; i < nx; i++) {
+        double s = rc[i];
+        for (int j = 0; j < nx; j++) s += A[i * nx + j] * dx[j];
+        for (int j = 0; j < nw; j++) s += Bm[i * nw + j] * dz[nx + j];
+        dxn[i] = s;
+      }
+      memcpy(dx, dxn, sizeof(double) * nx);
+    }
+  }
+  return 0;
+}
+
+/* merit pieces at a trial point (function values only):
+ * returns 0 ok, 1 rejected (bad avoidance row / non-finite) */
+static int trial_merit(const orc_desc *d, orc_work *w, const double *params, double mu,
+                       double *f_out, double *theta_out, double *logsum_out) {
+  const int N = w->N, nv = w->nv, nx = w->nx, m = w->m;
+  double f = 0, th = 0, ls = 0;
+  for (int k = 0; k < N; k++) {
+    double fk;
+    int r = orc_eval_stage(d, w->zt + (size_t)k * nv, params + (size_t)k * d->npar, 0, &fk, 0, 0,
+                           w->gt + (size_t)k * MRM, 0, k < N - 1 ? w->xnt + (size_t)k * nx : 0, 0, 0);
+    if (r < 0) return 1;
+    f += fk;
+    for (int i = 0; i < m; i++) {
+      th += fabs(w->gt[(size_t)k * MRM + i] - w->tt[(size_t)k * m + i]);
+      ls += log(w->tt[(size_t)k * m + i]);
+    }
+  }
+  for (int k = 0; k < N - 1; k++)
+    for (int i = 0; i < nx; i++) th += fabs(w->xnt[(size_t)k * nx + i] - w->zt[(size_t)(k + 1) * nv + i]);
+  (void)mu;
+  if (!isfinite(f) || !isfinite(th) || !isfinite(ls)) return 1;
+  *f_out = f; *theta_out = th; *logsum_out = ls;
+  return 0;
+}
+
+int orc_solve(const orc_desc *d, const double *xinit, const double *x0, const double *params,
+              double *zout, orc_stats *st, double *trace) {
+  int nh, m;
+  if (orc_num_rows(d, &nh, &m) != 0) return -1;
+  const int N = d->N, nx = d->nx, nv = nvar_of(d), nw = d->ns + d->nu;
+  if (nx > NXM || nw > NWM || nv > NVM || N < 1) return -1;
+  orc_work W, *w = &W;
+  work_alloc(w, d, m);
+  memcpy(w->z, x0, sizeof(double) * N * nv);
+  memcpy(w->z, xinit, sizeof(double) * nx); /* x_1 = xinit (mpcModel.py:108 xinitidx) */
+  memset(st, 0, sizeof *st);
+  double mu = d->mu0, rho = 0.0;
+  int exitflag = 0, it = 0;
+  int ev = eval_all(d, w, params);
+  if (ev != 0) { exitflag = (ev == ORC_EVAL_BAD_AVOID) ? -7 : -10; goto done; }
+  for (int k = 0; k < N; k++)
+    for (int i = 0; i < m; i++) {
+      double gv = w->g[(size_t)k * MRM + i];
+      double tv = gv > ORC_TMIN ? gv : ORC_TMIN;
+      w->t[(size_t)k * m + i] = tv;
+      w->lam[(size_t)k * m + i] = mu / tv;
+    }
+  for (it = 0;; it++) {
+    /* ---- residuals at the current iterate ---- */
+    double res_stat = 0, res_eq = 0, res_ineq = 0, res_comp = 0, obj = 0, theta = 0, logsum = 0;
+    for (int k = 0; k < N; k++) {
+      const double *Jg = w->Jg + (size_t)k * MRM * nv;
+      obj += w->f[k];
+      if (k < N - 1)
+        for (int i = 0; i < nx; i++) {
+          double r = w->xn[(size_t)k * nx + i] - w->z[(size_t)(k + 1) * nv + i];
+          w->rc[(size_t)k * nx + i] = r;
+          if (fabs(r) > res_eq) res_eq = fabs(r);
+          theta += fabs(r);
+        }
+      for (int i = 0; i < m; i++) {
+        double rg = w->g[(size_t)k * MRM + i] - w->t[(size_t)k * m + i];
+        if (fabs(rg) > res_ineq) res_ineq = fabs(rg);
+        theta += fabs(rg);
+        double c = w->t[(size_t)k * m + i] * w->lam[(size_t)k * m + i];
+        if (c > res_comp) res_comp = c;
+        logsum += log(w->t[(size_t)k * m + i]);
+      }
+      for (int a = 0; a < nv; a++) {
+        double r = w->gf[(size_t)k * nv + a];
+        for (int i = 0; i < m; i++) r -= Jg[i * nv + a] * w->lam[(size_t)k * m + i];
+        if (k < N - 1) {
+          const double *nun = w->nu + (size_t)(k + 1) * nx;
+          if (a < nx) { for (int l = 0; l < nx; l++) r += w->A[(size_t)k * nx * nx + l * nx + a] * nun[l]; }
+          else { for (int l = 0; l < nx; l++) r += w->Bm[(size_t)k * nx * nw + l * nw + (a - nx)] * nun[l]; }
+        }
+        if (a < nx) {
+          if (k == 0) continue; /* x_1 is fixed: no stationarity condition */
+          r -= w->nu[(size_t)k * nx + a];
+        }
+        if (fabs(r) > res_stat) res_stat = fabs(r);
+      }
+    }
+    st->res_stat = res_stat; st->res_eq = res_eq; st->res_ineq = res_ineq; st->res_comp = res_comp;
+    st->obj = obj; st->mu = mu;
+    if (trace) {
+      double *tr = trace + (size_t)it * ORC_TRACE_W;
+      tr[0] = res_stat; tr[1] = res_eq; tr[2] = res_ineq; tr[3] = res_comp; tr[4] = mu; tr[5] = 0; tr[6] = obj; tr[7] = 0;
+    }
+    if (!isfinite(res_stat) || !isfinite(res_eq) || !isfinite(res_ineq)) { exitflag = -6; break; }
+    if (res_stat <= d->tol_stat && res_eq <= d->tol_eq && res_ineq <= d->tol_ineq && res_comp <= d->tol_comp) {
+      exitflag = 1;
+      break;
+    }
+    if (it >= d->max_iter) { exitflag = 0; break; }
+    /* ---- condensed stage QPs ---- */
+    for (int k = 0; k < N; k++) {
+      const double *Jg = w->Jg + (size_t)k * MRM * nv;
+      double *Q = w->Q + (size_t)k * nv * nv, *qv = w->qv + (size_t)k * nv;
+      memcpy(Q, w->H + (size_t)k * nv * nv, sizeof(double) * nv * nv);
+      memcpy(qv, w->gf + (size_t)k * nv, sizeof(double) * nv);
+      for (int i = 0; i < m; i++) {
+        double tv = w->t[(size_t)k * m + i], lv = w->lam[(size_t)k * m + i];
+        double rg = w->g[(size_t)k * MRM + i] - tv;
+        double sig = lv / tv, cq = (mu - lv * rg) / tv;
+        const double *jr = Jg + i * nv;
+        for (int a = 0; a < nv; a++) {
+          if (jr[a] == 0.0) continue;
+          qv[a] -= jr[a] * cq;
+          for (int b = 0; b < nv; b++) Q[a * nv + b] += sig * jr[a] * jr[b];
+        }
+      }
+    }
+    if (riccati(w) != 0) { exitflag = -5; break; }
+    /* ---- slack / multiplier steps, fraction to the boundary ---- */
+    double ap = 1.0, ad = 1.0, gphi = 0.0;
+    for (int k = 0; k < N; k++) {
+      const double *Jg = w->Jg + (size_t)k * MRM * nv, *dz = w->dz + (size_t)k * nv;
+      for (int a = 0; a < nv; a++) gphi += w->gf[(size_t)k * nv + a] * dz[a];
+      for (int i = 0; i < m; i++) {
+        double tv = w->t[(size_t)k * m + i], lv = w->lam[(size_t)k * m + i];
+        double dt = w->g[(size_t)k * MRM + i] - tv;
+        for (int a = 0; a < nv; a++) dt += Jg[i * nv + a] * dz[a];
+        double dl = (mu - tv * lv - lv * dt) / tv;
+        w->dtt[(size_t)k * m + i] = dt;
+        w->dlam[(size_t)k * m + i] = dl;
+        if (dt < 0) { double a = -ORC_TAU * tv / dt; if (a < ap) ap = a; }
+        if (dl < 0) { double a = -ORC_TAU * lv / dl; if (a < ad) ad = a; }
+        gphi -= mu * dt / tv;
+      }
+    }
+    /* ---- l1 merit, Armijo backtracking ---- */
+    if (theta > 1e-13) {
+      double need = gphi / (0.9 * theta);
+      if (rho < need) rho = need + 1.0;
+    }
+    double D = gphi - rho * theta;
+    double phi0 = obj - mu * logsum + rho * theta;
+    double alpha = ap;
+    int ls = 0, accepted = 0;
+    for (ls = 0; ls <= ORC_LS_MAX; ls++) {
+      for (size_t i = 0; i < (size_t)N * nv; i++) w->zt[i] = w->z[i] + alpha * w->dz[i];
+      for (size_t i = 0; i < (size_t)N * m; i++) w->tt[i] = w->t[i] + alpha * w->dtt[i];
+      double ft, tht, lst;
+      if (trial_merit(d, w, params, mu, &ft, &tht, &lst) == 0) {
+        double phi = ft - mu * lst + rho * tht;
+        if (phi <= phi0 + ORC_ARMIJO * alpha * D + 1e-13 * fabs(phi0)) { accepted = 1; break; }
+      }
+      alpha *= 0.5;
+    }
+    if (!accepted) { exitflag = -8; break; } /* line search failure */
+    if (trace) { trace[(size_t)it * ORC_TRACE_W + 5] = alpha; trace[(size_t)it * ORC_TRACE_W + 7] = ls; }
+    memcpy(w->z, w->zt, sizeof(double) * N * nv);
+    memcpy(w->t, w->tt, sizeof(double) * N * m);
+    for (size_t i = 0; i < (size_t)N * m; i++) w->lam[i] += ad * w->dlam[i];
+    for (size_t i = 0; i < (size_t)N * nx; i++) w->nu[i] += alpha * (w->nunew[i] - w->nu[i]);
+    /* ---- barrier update: LOQO-style centrality rule with floor ---- */
+    {
+      double sum = 0, mn = 1e300;
+      size_t cnt = (size_t)N * m;
+      for (size_t i = 0; i < cnt; i++) {
+        double c = w->t[i] * w->lam[i];
+        sum += c;
+        if (c < mn) mn = c;
+      }
+      double avg = sum / (double)cnt;
+      double xi = mn / avg;
+      double sg = 0.05 * (1.0 - xi) / xi;
+      if (sg > 2.0) sg = 2.0;
+      sg = 0.1 * sg * sg * sg;
+      if (sg < 0.02) sg = 0.02; /* floor: never drop mu by more than 50x in one step */
+      if (sg > 0.8) sg = 0.8;
+      mu = sg * avg;
+      if (mu < 0.1 * d->tol_comp) mu = 0.1 * d->tol_comp;
+    }
+    if (!(mu < ORC_MU_DIVERGED)) { exitflag = -7; it++; break; } /* infeasible / diverged */
+    ev = eval_all(d, w, params);
+    if (ev != 0) { exitflag = (ev == ORC_EVAL_BAD_AVOID) ? -7 : -10; break; }
+  }
+done:
+  st->exitflag = exitflag;
+  st->iters = it;
+  memcpy(zout, w->z, sizeof(double) * N * nv);
+  work_free(w);
+  return 0;
+}
+
+int orc_solve_batch(const orc_desc *d, int B, const double *xinit, const double *x0,
+                    const double *params, double *zout, orc_stats *st, int nthreads) {
+  const int N = d->N, nx = d->nx, nv = nvar_of(d);
+  int err = 0;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+  (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int b = 0; b < B; b++) {
+    int r = orc_solve(d, xinit + (size_t)b * nx, x0 + (size_t)b * N * nv,
+                      params + (size_t)b * N * d->npar, zout + (size_t)b * N * nv, st + b, 0);
+    if (r != 0) err = r;
+  }
+  return err;
+}

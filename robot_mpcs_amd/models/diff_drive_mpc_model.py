@@ -1,0 +1,23 @@
+"""Diff-drive (boxer) MPC model.
+
+Mirror of reference ``robotmpcs/models/diff_drive_mpc_model.py``: state
+``x = [x, y, theta, xdot_w(3, carried, zero derivative), v, omega]`` (nx = 8),
+control ``u = [v_dot, omega_dot]``; continuous dynamics
+``[cos(theta) v, sin(theta) v, omega, 0, 0, 0, u0, u1]`` (``:24-41``),
+integrated by ERK2 (explicit midpoint) with 5 nodes in csrc/rmpc_model.hpp.
+"""
+from robot_mpcs_amd.models.mpcModel import MpcModel, ROBOT_DIFFDRIVE
+
+
+class MpcDiffDriveModel(MpcModel):
+    def __init__(self, initParamMap=True, **kwargs):
+        super().__init__(initParamMap=initParamMap, **kwargs)
+        self._n = self._fk.n() + 3
+        self._nx = 2 * self._n + 2
+        self._nu = 2 + self._fk.n()
+
+    def robot_kind(self):
+        return ROBOT_DIFFDRIVE
+
+    def get_velocity(self, z):
+        return z[2 * self._n: 2 * self._n + self._nu]
