@@ -1,0 +1,227 @@
+"""Independent numpy restatement of the reference NLP (TEST INFRASTRUCTURE).
+
+Written separately from ``rmpc_oracle.c`` (homogeneous 4x4 transforms instead
+of the recursive position/axis form, no analytic derivatives -- those are
+checked against central finite differences of these functions) so that the two
+oracles pin each other.  Also provides the scipy SLSQP cross-solve of the same
+NLP.  PARITY UNPINNED against the reference itself: see rmpc_oracle.h.
+
+Reference lines restated:
+  z layout              robotmpcs/models/mpcBase.py:76-80
+  obstacle distances    robotmpcs/models/mpcBase.py:82-101
+  double integrator     robotmpcs/models/mpcModel.py:65-69
+  unicycle              robotmpcs/models/diff_drive_mpc_model.py:24-41
+  ERK2, 5 nodes         robotmpcs/models/mpcModel.py:118-120 (explicit midpoint)
+  inequality modules    robotmpcs/models/inequalities/*.py
+  objectives            robotmpcs/models/objectives/{ObjectiveManager,goal_reaching,constraint_avoidance}.py
+  NLP assembly          robotmpcs/models/mpcModel.py:74-108
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RADIAL, LINEAR, SELFCOLL, JOINTLIM, VELLIM, INPUTLIM = range(6)
+FIXED, REVOLUTE, PRISMATIC = range(3)
+
+
+def _hom(R, t):
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return T
+
+
+def _axis_angle(ax, th):
+    ax = np.asarray(ax, dtype=float)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+
+def fk(desc, q, frame):
+    """Position of the frame attached to the child link of joint ``frame``."""
+    T = np.eye(4)
+    if desc["robot"] == 1:  # diff-drive base pose prefixes the chain
+        c, s = np.cos(q[2]), np.sin(q[2])
+        T = _hom(np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]]), np.array([q[0], q[1], 0.0]))
+    for j in desc["joints"][: frame + 1]:
+        T = T @ _hom(np.asarray(j["rot"], dtype=float).reshape(3, 3), np.asarray(j["xyz"], dtype=float))
+        if j["type"] == REVOLUTE:
+            T = T @ _hom(_axis_angle(j["axis"], q[j["dof"]]), np.zeros(3))
+        elif j["type"] == PRISMATIC:
+            T = T @ _hom(np.eye(3), np.asarray(j["axis"], dtype=float) * q[j["dof"]])
+    return T[:3, 3].copy()
+
+
+def cont_dyn(desc, x, u):
+    n = desc["n"]
+    if desc["robot"] == 0:
+        return np.concatenate([x[n: 2 * n], u])
+    th, v, w = x[2], x[6], x[7]
+    return np.array([np.cos(th) * v, np.sin(th) * v, w, 0.0, 0.0, 0.0, u[0], u[1]])
+
+
+def dynamics(desc, x, u, nodes=5):
+    h = desc["dt"] / nodes
+    x = np.array(x, dtype=float)
+    for _ in range(nodes):
+        k1 = cont_dyn(desc, x, u)
+        k2 = cont_dyn(desc, x + 0.5 * h * k1, u)
+        x = x + h * k2
+    return x
+
+
+def split(desc, z):
+    nx, ns, nu, n = desc["nx"], desc["ns"], desc["nu"], desc["n"]
+    return z[:n], z[:nx], (z[nx] if ns else 0.0), z[nx + ns: nx + ns + nu]
+
+
+def module_rows(desc, z, p):
+    """List (per module, YAML order) of un-slacked row values."""
+    q, x, s, u = split(desc, z)
+    nx, n, nu = desc["nx"], desc["n"], desc["nu"]
+    out = []
+    for kind in desc["module_kind"]:
+        rows = []
+        if kind == RADIAL:
+            rb = p[desc["off_r_body"]]
+            for fr in desc["link_frame"]:
+                pos = fk(desc, q, fr)
+                for i in range(desc["nobst"]):
+                    ob = p[desc["off_obst"] + 4 * i: desc["off_obst"] + 4 * i + 4]
+                    rows.append(np.linalg.norm(pos - ob[:3]) - ob[3] - rb)
+        elif kind == LINEAR:
+            rb = p[desc["off_r_body"]]
+            for fr in desc["link_frame"]:
+                pos = fk(desc, q, fr)
+                for i in range(desc["nobst"]):
+                    pl = p[desc["off_lin"] + 4 * i: desc["off_lin"] + 4 * i + 4]
+                    rows.append(abs(pl[:3] @ pos + pl[3]) / np.linalg.norm(pl[:3]) - rb)
+        elif kind == SELFCOLL:
+            rb = p[desc["off_r_body"]]
+            for a, b in desc["pair_frame"]:
+                rows.append(np.linalg.norm(fk(desc, q, a) - fk(desc, q, b)) - 2 * rb)
+        elif kind == JOINTLIM:
+            lo = p[desc["off_lower"]: desc["off_lower"] + n]
+            hi = p[desc["off_upper"]: desc["off_upper"] + n]
+            for j in range(n):
+                rows += [q[j] - lo[j], hi[j] - q[j]]
+        elif kind == VELLIM:
+            lo = p[desc["off_lower_vel"]: desc["off_lower_vel"] + 2]
+            hi = p[desc["off_upper_vel"]: desc["off_upper_vel"] + 2]
+            vel = z[n:nx][-2:]
+            for j in range(2):
+                rows += [vel[j] - lo[j], hi[j] - vel[j]]
+        elif kind == INPUTLIM:
+            lo = p[desc["off_lower_u"]: desc["off_lower_u"] + nu]
+            hi = p[desc["off_upper_u"]: desc["off_upper_u"] + nu]
+            for j in range(nu):
+                rows += [u[j] - lo[j], hi[j] - u[j]]
+        else:
+            raise ValueError(kind)
+        out.append(rows)
+    return out
+
+
+def stage_ineq(desc, z, p, with_bounds=True):
+    q, x, s, u = split(desc, z)
+    rows = [r for mod in module_rows(desc, z, p) for r in mod]
+    g = np.array(rows, dtype=float)
+    if desc["ns"]:
+        g = g + s
+    if with_bounds:
+        nv = desc["nx"] + desc["ns"] + desc["nu"]
+        lb, ub = np.asarray(desc["lb"][:nv], dtype=float), np.asarray(desc["ub"][:nv], dtype=float)
+        g = np.concatenate([g, (z - lb)[np.isfinite(lb)], (ub - z)[np.isfinite(ub)]])
+    return g
+
+
+def stage_cost(desc, z, p):
+    q, x, s, u = split(desc, z)
+    J = 0.0
+    if desc["has_goal"]:
+        e = fk(desc, q, desc["end_frame"]) - p[desc["off_goal"]: desc["off_goal"] + 3]
+        J += float(e @ (p[desc["off_wgoal"]: desc["off_wgoal"] + 3] * e))
+    if desc["has_avoid"]:
+        for i, rows in enumerate(module_rows(desc, z, p)):
+            w = p[desc["off_wconstr"] + i]
+            if rows and w != 0.0:
+                J += desc["N"] * w / rows[0]
+    wu = p[desc["off_wu"]: desc["off_wu"] + desc["nu"]]
+    J += float(u @ (wu * u))
+    if desc["ns"]:
+        J += p[desc["off_ws"]] * s * s
+    return J
+
+
+def fd_grad(fun, z, eps=1e-6):
+    z = np.asarray(z, dtype=float)
+    f0 = np.atleast_1d(fun(z))
+    out = np.zeros((f0.size, z.size))
+    for i in range(z.size):
+        zp, zm = z.copy(), z.copy()
+        zp[i] += eps
+        zm[i] -= eps
+        out[:, i] = (np.atleast_1d(fun(zp)) - np.atleast_1d(fun(zm))) / (2 * eps)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# whole-horizon NLP for scipy
+# ---------------------------------------------------------------------------
+class HorizonNLP:
+    """min sum_k l(z_k, p_k)  s.t. x_1 = xinit, x_{k+1} = Phi(x_k, u_k),
+    h(z_k, p_k) >= 0, lb <= z_k <= ub (reference mpcModel.py:74-108).
+    x_1 is eliminated (fixed to xinit); decision vector = [w_1, z_2 .. z_N]."""
+
+    def __init__(self, desc, xinit, params):
+        self.d = desc
+        self.N = desc["N"]
+        self.nx, self.ns, self.nu = desc["nx"], desc["ns"], desc["nu"]
+        self.nv = self.nx + self.ns + self.nu
+        self.nw = self.ns + self.nu
+        self.xinit = np.asarray(xinit, dtype=float)
+        self.P = np.asarray(params, dtype=float).reshape(self.N, desc["npar"])
+
+    def unpack(self, y):
+        Z = np.zeros((self.N, self.nv))
+        Z[0, : self.nx] = self.xinit
+        Z[0, self.nx:] = y[: self.nw]
+        Z[1:] = y[self.nw:].reshape(self.N - 1, self.nv)
+        return Z
+
+    def pack(self, Z):
+        return np.concatenate([Z[0, self.nx:], Z[1:].reshape(-1)])
+
+    def objective(self, y):
+        Z = self.unpack(y)
+        return sum(stage_cost(self.d, Z[k], self.P[k]) for k in range(self.N))
+
+    def eq(self, y):
+        Z = self.unpack(y)
+        r = []
+        for k in range(self.N - 1):
+            u = Z[k, self.nx + self.ns:]
+            r.append(dynamics(self.d, Z[k, : self.nx], u) - Z[k + 1, : self.nx])
+        return np.concatenate(r) if r else np.zeros(0)
+
+    def ineq(self, y):
+        Z = self.unpack(y)
+        return np.concatenate([stage_ineq(self.d, Z[k], self.P[k], with_bounds=False) for k in range(self.N)])
+
+    def bounds(self):
+        nv = self.nv
+        lb, ub = np.asarray(self.d["lb"][:nv], dtype=float), np.asarray(self.d["ub"][:nv], dtype=float)
+        lo = np.concatenate([lb[self.nx:], np.tile(lb, self.N - 1)])
+        hi = np.concatenate([ub[self.nx:], np.tile(ub, self.N - 1)])
+        return [(a if np.isfinite(a) else None, b if np.isfinite(b) else None) for a, b in zip(lo, hi)]
+
+    def solve_slsqp(self, Z0, maxiter=500, ftol=1e-12):
+        from scipy.optimize import minimize
+
+        y0 = self.pack(np.asarray(Z0, dtype=float).reshape(self.N, self.nv))
+        res = minimize(
+            self.objective, y0, method="SLSQP", bounds=self.bounds(),
+            constraints=[{"type": "eq", "fun": self.eq}, {"type": "ineq", "fun": self.ineq}],
+            options={"maxiter": maxiter, "ftol": ftol},
+        )
+        return self.unpack(res.x), res

@@ -1,0 +1,132 @@
+"""Pins the C oracle's model functions (oracle/rmpc_oracle.c) against the
+independent numpy restatement (oracle/nlp_numpy.py), central finite
+differences, and a sympy derivation of the panda kinematics.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import nlp_numpy as ref
+from oracle.oracle import Oracle
+from robot_mpcs_amd.scenarios import make_scenario
+
+CASES = ["cfg1", "cfg2", "cfg3", "cfg4", "boxer"]
+
+
+def _random_points(sc, o, rng, k=6):
+    """random stage points around the scenario's start state, obstacle-free side"""
+    pts = []
+    for i in range(k):
+        b = i % sc.B
+        z = sc.x0[b, 0].copy()
+        z[: o.nx] += rng.normal(0, 0.15, o.nx)
+        if o.ns:
+            z[o.nx] = abs(rng.normal(0, 0.1))
+        z[o.nx + o.ns:] = rng.normal(0, 0.5, o.nu)
+        kk = rng.integers(0, o.N)
+        pts.append((z, sc.params[b].reshape(o.N, o.npar)[kk]))
+    return pts
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_values_match_numpy(name, oracle_lib):
+    sc = make_scenario(name, B=4, seed=3)
+    o = Oracle(sc.desc)
+    rng = np.random.default_rng(0)
+    for z, p in _random_points(sc, o, rng):
+        e = o.eval_stage(z, p)
+        assert e["rows"] == o.m
+        np.testing.assert_allclose(e["f"], ref.stage_cost(sc.desc, z, p), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(e["g"], ref.stage_ineq(sc.desc, z, p), rtol=1e-12, atol=1e-12)
+        u = z[o.nx + o.ns:]
+        np.testing.assert_allclose(e["xnext"], ref.dynamics(sc.desc, z[: o.nx], u), rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_derivatives_match_finite_differences(name, oracle_lib):
+    sc = make_scenario(name, B=4, seed=4)
+    o = Oracle(sc.desc)
+    d = sc.desc
+    rng = np.random.default_rng(1)
+    for z, p in _random_points(sc, o, rng, k=4):
+        e = o.eval_stage(z, p)
+        gfd = ref.fd_grad(lambda zz: ref.stage_cost(d, zz, p), z)[0]
+        np.testing.assert_allclose(e["gf"], gfd, rtol=2e-6, atol=2e-6 * max(1.0, np.abs(gfd).max()))
+        Jfd = ref.fd_grad(lambda zz: ref.stage_ineq(d, zz, p), z)
+        np.testing.assert_allclose(e["Jg"], Jfd, rtol=1e-6, atol=1e-7)
+        nx, ns = o.nx, o.ns
+        Afd = ref.fd_grad(lambda xx: ref.dynamics(d, xx, z[nx + ns:]), z[:nx])
+        Bfd = ref.fd_grad(lambda uu: ref.dynamics(d, z[:nx], uu), z[nx + ns:])
+        np.testing.assert_allclose(e["A"], Afd, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(e["B"][:, ns:], Bfd, rtol=1e-6, atol=1e-8)
+        if ns:
+            assert np.all(e["B"][:, :ns] == 0.0)
+        # generalised Gauss-Newton Hessian: symmetric, PSD
+        H = e["H"]
+        np.testing.assert_allclose(H, H.T, atol=1e-12 * max(1.0, np.abs(H).max()))
+        assert np.linalg.eigvalsh(H).min() > -1e-9 * max(1.0, np.abs(H).max())
+
+
+def test_ggn_hessian_is_exact_for_point_robot_without_avoidance(oracle_lib):
+    """pointRobot FK is linear, so without the 1/h terms the GGN Hessian is the
+    exact Hessian of the stage cost."""
+    sc = make_scenario("cfg1", B=1)
+    d = dict(sc.desc)
+    d["has_avoid"] = 0
+    o = Oracle(d)
+    rng = np.random.default_rng(2)
+    z = sc.x0[0, 0] + rng.normal(0, 0.3, o.nv)
+    p = sc.params[0, : o.npar]
+    e = o.eval_stage(z, p)
+    Hfd = ref.fd_grad(lambda zz: ref.fd_grad(lambda y: ref.stage_cost(d, y, p), zz, 1e-4)[0], z, 1e-4)
+    np.testing.assert_allclose(e["H"], Hfd, atol=1e-5)
+
+
+def test_panda_fk_against_sympy(oracle_lib):
+    """Symbolic chain product built from hard-coded Franka constants (SURVEY.md
+    8a row A-FK), independent of the URDF parser, vs. the C oracle."""
+    sp = pytest.importorskip("sympy")
+    hp = 1.57079632679
+    rows = [((0, 0, 0.333), 0.0), ((0, 0, 0), -hp), ((0, -0.316, 0), hp), ((0.0825, 0, 0), hp),
+            ((-0.0825, 0.384, 0), -hp), ((0, 0, 0), hp), ((0.088, 0, 0), hp)]
+    q = sp.symbols("q0:7")
+    T = sp.eye(4)
+    frames = []
+    for i, (xyz, roll) in enumerate(rows):
+        Rx = sp.Matrix([[1, 0, 0, xyz[0]], [0, sp.cos(roll), -sp.sin(roll), xyz[1]],
+                        [0, sp.sin(roll), sp.cos(roll), xyz[2]], [0, 0, 0, 1]])
+        Rz = sp.Matrix([[sp.cos(q[i]), -sp.sin(q[i]), 0, 0], [sp.sin(q[i]), sp.cos(q[i]), 0, 0],
+                        [0, 0, 1, 0], [0, 0, 0, 1]])
+        T = T * Rx * Rz
+        frames.append(T[:3, 3])
+    sc = make_scenario("cfg4", B=1)
+    o = Oracle(sc.desc)
+    rng = np.random.default_rng(5)
+    for fr in (2, 4, 6):
+        pos_fn = sp.lambdify(q, frames[fr], "numpy")
+        jac_fn = sp.lambdify(q, frames[fr].jacobian(sp.Matrix(q)), "numpy")
+        for _ in range(3):
+            qv = rng.uniform(-1.5, 1.5, 7)
+            pos, J = o.fk(qv, fr)
+            np.testing.assert_allclose(pos, np.asarray(pos_fn(*qv), dtype=float).ravel(), atol=1e-12)
+            np.testing.assert_allclose(J, np.asarray(jac_fn(*qv), dtype=float), atol=1e-12)
+
+
+def test_param_map_layout_matches_survey():
+    """paramMap index layout of the shipped configs."""
+    sc = make_scenario("pointRobot", B=1)
+    pm = sc.model._paramMap
+    assert pm["r_body"] == [0] and pm["obst"] == [1, 2, 3, 4]
+    assert pm["lower_limits"] == [5, 6, 7] and pm["upper_limits"] == [8, 9, 10]
+    assert pm["lower_limits_u"] == [11, 12, 13] and pm["upper_limits_u"] == [14, 15, 16]
+    assert pm["wu"] == [17, 18, 19] and pm["goal"] == [20, 21, 22] and pm["wgoal"] == [23, 24, 25]
+    assert pm["wconstr"] == [26, 27, 28, 29] and sc.model._npar == 30
+    sc = make_scenario("panda", B=1)
+    assert sc.model._npar == 50 and sc.model._paramMap["wconstr"] == [46, 47, 48, 49]
+    assert sc.model.number_inequalities == 32
+    sc = make_scenario("boxer", B=1)
+    pm = sc.model._paramMap
+    assert sc.model._npar == 27 and pm["lin_constrs_0"] == [1, 2, 3, 4] and pm["wu"] == [15, 16]
+    assert sc.model.number_inequalities == 11
+    sc = make_scenario("cfg2", B=1)
+    assert sc.model._npar == 38 and sc.model.number_inequalities == 15
+    sc = make_scenario("cfg3", B=1)
+    assert sc.model._npar == 44 and sc.model._ns == 1 and sc.model.number_inequalities == 15

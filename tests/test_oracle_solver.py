@@ -1,0 +1,72 @@
+"""Pins the C oracle's solver against an independent scipy SLSQP solve of the
+same NLP (oracle/nlp_numpy.py) and checks solver-level properties.  CPU only.
+Tolerance vs scipy: 1e-4 on z when both converge to the same basin
+(SURVEY.md 8c); slack configs (ws = 1e10) are compared at 1e-3 because SLSQP
+stops early on them (status 8)."""
+import numpy as np
+import pytest
+
+from oracle import nlp_numpy as ref
+from oracle.oracle import Oracle
+from robot_mpcs_amd.scenarios import make_scenario
+
+CROSS = [
+    ("cfg1", {}, 1e-4),
+    ("cfg2", dict(time_horizon=6), 1e-4),
+    ("boxer", dict(time_horizon=6), 1e-4),
+    ("cfg3", dict(time_horizon=5), 1e-3),
+    ("cfg4", dict(time_horizon=4), 1e-4),
+]
+
+
+@pytest.mark.parametrize("name,over,tol", CROSS)
+def test_oracle_matches_scipy_slsqp(name, over, tol, oracle_lib):
+    sc = make_scenario(name, B=2, seed=7, **over)
+    o = Oracle(sc.desc)
+    b = 0
+    r = o.solve(sc.xinit[b], sc.x0[b], sc.params[b])
+    assert r["exitflag"] == 1
+    nlp = ref.HorizonNLP(sc.desc, sc.xinit[b], sc.params[b])
+    Zs, res = nlp.solve_slsqp(sc.x0[b])
+    assert res.status in (0, 8)
+    assert abs(res.fun - r["obj"]) <= 1e-6 * max(1.0, abs(res.fun))
+    nxs = o.nx + o.ns
+    np.testing.assert_allclose(r["z"][0, nxs:], Zs[0, nxs:], atol=tol)  # applied control u_1
+    np.testing.assert_allclose(r["z"], Zs, atol=10 * tol)               # whole plan (flat directions)
+    # oracle solution is feasible for the independent restatement
+    y = nlp.pack(r["z"])
+    assert np.abs(nlp.eq(y)).max() < 1e-7
+    assert nlp.ineq(y).min() > -1e-7
+
+
+@pytest.mark.parametrize("name,B", [("cfg2", 64), ("cfg3", 64), ("cfg4", 32)])
+def test_batch_converges_and_is_order_independent(name, B, oracle_lib):
+    sc = make_scenario(name, B=B, seed=11)
+    o = Oracle(sc.desc)
+    r = o.solve_batch(sc.xinit, sc.x0, sc.params)
+    assert np.all(r["exitflag"] == 1)
+    assert r["res_stat"].max() <= 1e-6 and r["res_eq"].max() <= 1e-8 and r["res_comp"].max() <= 1e-6
+    perm = np.random.default_rng(0).permutation(B)
+    rp = o.solve_batch(sc.xinit[perm], sc.x0[perm], sc.params[perm], nthreads=3)
+    assert np.array_equal(rp["z"], r["z"][perm])  # bit-identical, any thread count
+    assert np.array_equal(rp["iters"], r["iters"][perm])
+
+
+def test_first_stage_state_is_xinit_and_inputs_respect_limits(oracle_lib):
+    sc = make_scenario("cfg2", B=16, seed=5)
+    o = Oracle(sc.desc)
+    r = o.solve_batch(sc.xinit, sc.x0, sc.params)
+    assert np.array_equal(r["z"][:, 0, : o.nx], sc.xinit)
+    u = r["z"][:, :, o.nx:]
+    assert np.all(np.abs(u[:, :, 0:2]) <= 1.0 + 1e-9)
+
+
+def test_infeasible_start_reports_negative_exitflag(oracle_lib):
+    sc = make_scenario("cfg1", B=1)
+    xinit = sc.xinit[0].copy()
+    xinit[0:2] = [4.0, -0.5]  # inside the obstacle
+    x0 = sc.x0[0].copy()
+    x0[:, :6] = xinit
+    o = Oracle(sc.desc)
+    r = o.solve(xinit, x0, sc.params[0])
+    assert r["exitflag"] < 0
