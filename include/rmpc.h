@@ -1,0 +1,153 @@
+/*
+ * rmpc.h -- C ABI of the MI355X batched MPC solver (librmpc_hip.so).
+ *
+ * Drop-in boundary for the one native call the reference planner makes per
+ * control step:
+ *
+ *   forcespro.nlp.Solver.from_directory(dir)            robotmpcs/planner/mpcPlanner.py:73
+ *   output, exitflag, info = solver.solve(problem)      robotmpcs/planner/mpcPlanner.py:262
+ *     problem = { "xinit": (nx,), "x0": (N*nvar,), "all_parameters": (N*npar,) }   :246-250
+ *     output  = { "x01": (nvar,), ... }                                            :265-281
+ *
+ * The FORCES Pro generated solver is a per-model shared object loaded through
+ * ctypes; this library is its replacement with a leading batch axis B.  Plain
+ * pointers and sizes only -- no torch / numpy types cross this boundary.
+ *
+ * Layout at the ABI (row-major, instance-major, exactly x0.flatten() of the
+ * reference, mpcPlanner.py:249):
+ *   xinit  [B][nx]
+ *   x0     [B][N][nvar]      nvar = nx + ns + nu, stage vector z = [x; s; u]   (mpcBase.py:76-80)
+ *   params [B][N][npar]      stride npar per stage                             (mpcPlanner.py:91-104)
+ *   z_out  [B][N][nvar]      row k = output["x%0*d" % (k+1)]                    (mpcPlanner.py:265-273)
+ *
+ * Ownership: the caller owns every in/out buffer; the library owns the handle
+ * and its device workspace and keeps no caller pointer past return.
+ * Threading: a handle is not thread-safe; distinct handles (one per GPU) may be
+ * driven from distinct host threads or processes.
+ * Errors: functions return 0 on success, non-zero on API misuse or HIP errors
+ * (text via rmpc_last_error()).  Solver outcomes are per instance in exitflag:
+ *    1 converged, 0 iteration cap reached (plan still usable),
+ *   <0 failure (-5 factorisation, -6 non-finite, -7 infeasible/diverged,
+ *      -8 line search) -- the planner only tests the sign (mpcPlanner.py:263,
+ *      examples/boxer_example.py:194).
+ */
+#ifndef RMPC_H
+#define RMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMPC_VERSION 100 /* 0.1.0 */
+
+#define RMPC_MAX_JOINTS 8
+#define RMPC_MAX_LINKS 8
+#define RMPC_MAX_PAIRS 4
+#define RMPC_MAX_MODULES 8
+#define RMPC_NV_MAX 24
+
+/* robot kinds (base_type in the YAML, mpcBase.py:52-60) */
+#define RMPC_ROBOT_CHAIN 0     /* holonomic URDF chain: nx = 2n, nu = n (mpcModel.py:65-69) */
+#define RMPC_ROBOT_DIFFDRIVE 1 /* diff-drive base, fk.n() == 0 (diff_drive_mpc_model.py:24-41) */
+
+/* inequality modules = YAML class names (models/inequalities/__init__.py) */
+#define RMPC_MOD_RADIAL 0
+#define RMPC_MOD_LINEAR 1
+#define RMPC_MOD_SELFCOLLISION 2
+#define RMPC_MOD_JOINTLIMIT 3
+#define RMPC_MOD_VELLIMIT 4
+#define RMPC_MOD_INPUTLIMIT 5
+
+#define RMPC_JOINT_FIXED 0
+#define RMPC_JOINT_REVOLUTE 1
+#define RMPC_JOINT_PRISMATIC 2
+
+/* Model descriptor: the numeric content of <solver dir>/rmpc_model.yaml, i.e.
+ * what the reference encodes in the generated solver (mpcModel.py:74-126). */
+typedef struct rmpc_desc {
+  int32_t struct_size; /* sizeof(rmpc_desc), checked */
+  int32_t device;      /* HIP device ordinal */
+  int32_t robot;
+  int32_t N;           /* horizon (time_horizon) */
+  int32_t n, nx, nu, ns, npar;
+  double dt;           /* time_step; integrator ERK2 (explicit midpoint), 5 nodes */
+  int32_t n_modules;
+  int32_t module_kind[RMPC_MAX_MODULES];
+  int32_t nobst;       /* number_obstacles */
+  int32_t n_links;
+  int32_t link_frame[RMPC_MAX_LINKS];
+  int32_t n_pairs;
+  int32_t pair_frame[RMPC_MAX_PAIRS][2];
+  int32_t end_frame;
+  int32_t n_joints;
+  int32_t joint_type[RMPC_MAX_JOINTS];
+  int32_t joint_dof[RMPC_MAX_JOINTS];
+  double joint_xyz[RMPC_MAX_JOINTS][3];
+  double joint_rot[RMPC_MAX_JOINTS][9];
+  double joint_axis[RMPC_MAX_JOINTS][3];
+  /* offsets into one stage's parameter slice (paramMap.yaml), -1 = absent */
+  int32_t off_r_body, off_obst, off_lin, off_lower, off_upper, off_lower_u,
+      off_upper_u, off_lower_vel, off_upper_vel, off_wu, off_goal, off_wgoal,
+      off_wconstr, off_ws;
+  int32_t has_goal, has_avoid;
+  double lb[RMPC_NV_MAX], ub[RMPC_NV_MAX]; /* z bounds, +-inf allowed (mpcModel.py:91-104) */
+  /* solver options */
+  int32_t max_iter;
+  double tol_stat, tol_eq, tol_ineq, tol_comp;
+  double mu0;
+} rmpc_desc;
+
+typedef struct rmpc_handle rmpc_handle;
+
+int rmpc_version(void);
+const char *rmpc_last_error(void);
+int rmpc_desc_size(void);
+
+/* Replaces forcespro.nlp.Solver.from_directory (mpcPlanner.py:73): validates
+ * the descriptor, selects the device and allocates the HBM workspace for up to
+ * max_batch instances. */
+int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out);
+void rmpc_destroy(rmpc_handle *h);
+
+/* Replaces solver.solve(problem) (mpcPlanner.py:262) for B instances; host
+ * pointers, blocks until the results are in host memory. */
+int rmpc_solve_batch(rmpc_handle *h, int B, const double *xinit, const double *x0,
+                     const double *params, double *z_out, int32_t *exitflag,
+                     int32_t *iters, double *kkt_res, double *obj);
+
+/* Same, device pointers (e.g. torch tensor data_ptr()).  All work is enqueued
+ * on `stream` (a hipStream_t; NULL = the handle's own stream); returns after
+ * the final kernel is enqueued and the iteration loop has drained. */
+int rmpc_solve_batch_device(rmpc_handle *h, int B, const double *d_xinit,
+                            const double *d_x0, const double *d_params,
+                            double *d_z_out, int32_t *d_exitflag, int32_t *d_iters,
+                            double *d_kkt_res, double *d_obj, void *stream);
+
+/* Workspace size in bytes for a given descriptor / batch (no allocation). */
+int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch);
+
+/* Per-kernel timing with HIP events on the solver's stream.
+ * kernels: 0 pack, 1 sweep, 2 riccati, 3 step, 4 unpack. */
+#define RMPC_NUM_KERNELS 5
+int rmpc_set_profiling(rmpc_handle *h, int enable);
+int rmpc_get_profile(rmpc_handle *h, double *total_ms, int64_t *launches,
+                     int64_t *algorithmic_bytes_per_launch);
+const char *rmpc_kernel_name(int idx);
+/* number of sweep/riccati/step passes of the last solve, and instance-iterations */
+int rmpc_last_passes(rmpc_handle *h);
+
+/* Debug / parity hooks (used by tests through the same ABI): evaluate one
+ * stage-parallel sweep at z = x0 (first-pass semantics) and return the
+ * condensed stage blocks in instance-major order.
+ * out_Q [B][N][nvar*nvar] dense symmetric, out_q0/out_q1 [B][N][nvar],
+ * out_rc [B][N][nx], out_g [B][N][nh], out_f [B][N]. */
+int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x0,
+                     const double *params, double *out_Q, double *out_q0,
+                     double *out_q1, double *out_rc, double *out_g, double *out_f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,237 @@
+"""ctypes binding of the MI355X solver library (``csrc/librmpc_hip.so``).
+
+This is the thin host layer above the C ABI declared in ``include/rmpc.h``;
+it plays the role ``forcespro.nlp.Solver`` plays for the reference planner
+(``robotmpcs/planner/mpcPlanner.py:73,262``).  There is no CPU fallback: if the
+library is missing or no HIP device is present the constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librmpc_hip.so")
+
+MAX_JOINTS, MAX_LINKS, MAX_PAIRS, MAX_MODULES, NV_MAX = 8, 8, 4, 8, 24
+NUM_KERNELS = 5
+
+
+class RmpcError(RuntimeError):
+    pass
+
+
+class RmpcDesc(C.Structure):
+    """Mirror of ``rmpc_desc`` (include/rmpc.h)."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32),
+        ("robot", C.c_int32), ("N", C.c_int32),
+        ("n", C.c_int32), ("nx", C.c_int32), ("nu", C.c_int32), ("ns", C.c_int32), ("npar", C.c_int32),
+        ("dt", C.c_double),
+        ("n_modules", C.c_int32), ("module_kind", C.c_int32 * MAX_MODULES),
+        ("nobst", C.c_int32),
+        ("n_links", C.c_int32), ("link_frame", C.c_int32 * MAX_LINKS),
+        ("n_pairs", C.c_int32), ("pair_frame", (C.c_int32 * 2) * MAX_PAIRS),
+        ("end_frame", C.c_int32),
+        ("n_joints", C.c_int32), ("joint_type", C.c_int32 * MAX_JOINTS), ("joint_dof", C.c_int32 * MAX_JOINTS),
+        ("joint_xyz", (C.c_double * 3) * MAX_JOINTS), ("joint_rot", (C.c_double * 9) * MAX_JOINTS),
+        ("joint_axis", (C.c_double * 3) * MAX_JOINTS),
+        ("off_r_body", C.c_int32), ("off_obst", C.c_int32), ("off_lin", C.c_int32),
+        ("off_lower", C.c_int32), ("off_upper", C.c_int32), ("off_lower_u", C.c_int32),
+        ("off_upper_u", C.c_int32), ("off_lower_vel", C.c_int32), ("off_upper_vel", C.c_int32),
+        ("off_wu", C.c_int32), ("off_goal", C.c_int32), ("off_wgoal", C.c_int32),
+        ("off_wconstr", C.c_int32), ("off_ws", C.c_int32),
+        ("has_goal", C.c_int32), ("has_avoid", C.c_int32),
+        ("lb", C.c_double * NV_MAX), ("ub", C.c_double * NV_MAX),
+        ("max_iter", C.c_int32),
+        ("tol_stat", C.c_double), ("tol_eq", C.c_double), ("tol_ineq", C.c_double), ("tol_comp", C.c_double),
+        ("mu0", C.c_double),
+    ]
+
+
+# every symbol include/rmpc.h declares
+EXPORTED_SYMBOLS = [
+    "rmpc_version", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
+    "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_profiling", "rmpc_get_profile",
+    "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep",
+]
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the HIP library; raises ``RmpcError`` when it has not been built
+    (``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RmpcError(f"{path} not found: build the HIP extension first (__graft_entry__.build())")
+    L = C.CDLL(path)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    L.rmpc_version.restype = C.c_int
+    L.rmpc_last_error.restype = C.c_char_p
+    L.rmpc_desc_size.restype = C.c_int
+    L.rmpc_create.restype = C.c_int
+    L.rmpc_create.argtypes = [C.POINTER(RmpcDesc), C.c_int, C.POINTER(C.c_void_p)]
+    L.rmpc_destroy.restype = None
+    L.rmpc_destroy.argtypes = [C.c_void_p]
+    L.rmpc_solve_batch.restype = C.c_int
+    L.rmpc_solve_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, ip, ip, dp, dp]
+    L.rmpc_solve_batch_device.restype = C.c_int
+    L.rmpc_solve_batch_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9
+    L.rmpc_workspace_bytes.restype = C.c_int64
+    L.rmpc_workspace_bytes.argtypes = [C.POINTER(RmpcDesc), C.c_int]
+    L.rmpc_set_profiling.restype = C.c_int
+    L.rmpc_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.rmpc_get_profile.restype = C.c_int
+    L.rmpc_get_profile.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.rmpc_kernel_name.restype = C.c_char_p
+    L.rmpc_kernel_name.argtypes = [C.c_int]
+    L.rmpc_last_passes.restype = C.c_int
+    L.rmpc_last_passes.argtypes = [C.c_void_p]
+    L.rmpc_debug_sweep.restype = C.c_int
+    L.rmpc_debug_sweep.argtypes = [C.c_void_p, C.c_int] + [dp] * 9
+    if L.rmpc_desc_size() != C.sizeof(RmpcDesc):
+        raise RmpcError("rmpc_desc layout mismatch between _lib.py and librmpc_hip.so")
+    _lib = L
+    return L
+
+
+def make_desc(d: dict, device: int = 0) -> RmpcDesc:
+    """Descriptor dict (``rmpc_model.yaml``) -> ``rmpc_desc``."""
+    o = RmpcDesc()
+    o.struct_size = C.sizeof(RmpcDesc)
+    o.device = int(device)
+    o.robot = d["robot"]; o.N = d["N"]
+    o.n, o.nx, o.nu, o.ns, o.npar = d["n"], d["nx"], d["nu"], d["ns"], d["npar"]
+    o.dt = d["dt"]
+    if len(d["module_kind"]) > MAX_MODULES or len(d["link_frame"]) > MAX_LINKS or \
+            len(d["pair_frame"]) > MAX_PAIRS or len(d["joints"]) > MAX_JOINTS:
+        raise RmpcError("descriptor exceeds the ABI's fixed capacities")
+    o.n_modules = len(d["module_kind"])
+    for i, k in enumerate(d["module_kind"]):
+        o.module_kind[i] = k
+    o.nobst = d["nobst"]
+    o.n_links = len(d["link_frame"])
+    for i, f in enumerate(d["link_frame"]):
+        o.link_frame[i] = f
+    o.n_pairs = len(d["pair_frame"])
+    for i, (a, b) in enumerate(d["pair_frame"]):
+        o.pair_frame[i][0] = a; o.pair_frame[i][1] = b
+    o.end_frame = d["end_frame"]
+    o.n_joints = len(d["joints"])
+    for i, j in enumerate(d["joints"]):
+        o.joint_type[i] = j["type"]; o.joint_dof[i] = j["dof"]
+        for c in range(3):
+            o.joint_xyz[i][c] = j["xyz"][c]; o.joint_axis[i][c] = j["axis"][c]
+        for c in range(9):
+            o.joint_rot[i][c] = j["rot"][c]
+    for k in ("off_r_body", "off_obst", "off_lin", "off_lower", "off_upper", "off_lower_u", "off_upper_u",
+              "off_lower_vel", "off_upper_vel", "off_wu", "off_goal", "off_wgoal", "off_wconstr", "off_ws",
+              "has_goal", "has_avoid"):
+        setattr(o, k, d[k])
+    nv = d["nx"] + d["ns"] + d["nu"]
+    for i in range(NV_MAX):
+        o.lb[i] = float(d["lb"][i]) if i < nv else -np.inf
+        o.ub[i] = float(d["ub"][i]) if i < nv else np.inf
+    opt = d.get("options", {})
+    o.max_iter = int(opt.get("max_iter", 200))
+    o.tol_stat = float(opt.get("tol_stat", 1e-6)); o.tol_eq = float(opt.get("tol_eq", 1e-8))
+    o.tol_ineq = float(opt.get("tol_ineq", 1e-8)); o.tol_comp = float(opt.get("tol_comp", 1e-6))
+    o.mu0 = float(opt.get("mu0", 1.0))
+    return o
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Solver:
+    """One handle = one model on one GPU (``rmpc_create`` / ``rmpc_destroy``)."""
+
+    def __init__(self, desc: dict, max_batch: int = 1, device: int = 0):
+        self._L = load_library()
+        self.desc = desc
+        self.cdesc = make_desc(desc, device)
+        self.N, self.nx, self.nu, self.ns, self.npar = desc["N"], desc["nx"], desc["nu"], desc["ns"], desc["npar"]
+        self.nvar = self.nx + self.ns + self.nu
+        self.max_batch = int(max_batch)
+        self.device = int(device)
+        h = C.c_void_p()
+        rc = self._L.rmpc_create(C.byref(self.cdesc), self.max_batch, C.byref(h))
+        if rc != 0:
+            raise RmpcError("rmpc_create failed: " + self._L.rmpc_last_error().decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rmpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RmpcError(f"{what} failed: " + self._L.rmpc_last_error().decode())
+
+    def workspace_bytes(self) -> int:
+        return int(self._L.rmpc_workspace_bytes(C.byref(self.cdesc), self.max_batch))
+
+    # -- host buffers (numpy) ------------------------------------------------
+    def solve(self, xinit, x0, params):
+        xinit = np.ascontiguousarray(xinit, dtype=np.float64).reshape(-1, self.nx)
+        B = xinit.shape[0]
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(B, self.N * self.nvar)
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(B, self.N * self.npar)
+        z = np.empty((B, self.N, self.nvar))
+        exitflag = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32)
+        kkt = np.empty(B); obj = np.empty(B)
+        rc = self._L.rmpc_solve_batch(self._h, B, _dp(xinit), _dp(x0), _dp(params), _dp(z), _ip(exitflag),
+                                      _ip(iters), _dp(kkt), _dp(obj))
+        self._check(rc, "rmpc_solve_batch")
+        return dict(z=z, exitflag=exitflag, iters=iters, kkt=kkt, obj=obj)
+
+    # -- device buffers (anything exposing data_ptr(), e.g. torch tensors) ---------
+    def solve_device(self, B, xinit, x0, params, z_out, exitflag, iters, kkt, obj, stream=None):
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        st = C.c_void_p(int(stream)) if stream else C.c_void_p(0)
+        rc = self._L.rmpc_solve_batch_device(self._h, int(B), ptr(xinit), ptr(x0), ptr(params), ptr(z_out),
+                                             ptr(exitflag), ptr(iters), ptr(kkt), ptr(obj), st)
+        self._check(rc, "rmpc_solve_batch_device")
+
+    def set_profiling(self, enable: bool):
+        self._check(self._L.rmpc_set_profiling(self._h, 1 if enable else 0), "rmpc_set_profiling")
+
+    def get_profile(self):
+        ms = (C.c_double * NUM_KERNELS)(); n = (C.c_int64 * NUM_KERNELS)(); by = (C.c_int64 * NUM_KERNELS)()
+        self._check(self._L.rmpc_get_profile(self._h, ms, n, by), "rmpc_get_profile")
+        return {self._L.rmpc_kernel_name(i).decode(): dict(total_ms=ms[i], launches=n[i], alg_bytes_per_launch=by[i])
+                for i in range(NUM_KERNELS)}
+
+    def last_passes(self) -> int:
+        return int(self._L.rmpc_last_passes(self._h))
+
+    def debug_sweep(self, xinit, x0, params):
+        xinit = np.ascontiguousarray(xinit, dtype=np.float64).reshape(-1, self.nx)
+        B = xinit.shape[0]
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(B, self.N * self.nvar)
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(B, self.N * self.npar)
+        nv, N = self.nvar, self.N
+        nh = int(self.desc["nh"])
+        Q = np.zeros((B, N, nv, nv)); q0 = np.zeros((B, N, nv)); q1 = np.zeros((B, N, nv))
+        rc_ = np.zeros((B, N, self.nx)); g = np.zeros((B, N, max(nh, 1))); f = np.zeros((B, N))
+        rc = self._L.rmpc_debug_sweep(self._h, B, _dp(xinit), _dp(x0), _dp(params), _dp(Q), _dp(q0), _dp(q1),
+                                      _dp(rc_), _dp(g), _dp(f))
+        self._check(rc, "rmpc_debug_sweep")
+        return dict(Q=Q, q0=q0, q1=q1, rc=rc_, g=g[:, :, :nh], f=f)

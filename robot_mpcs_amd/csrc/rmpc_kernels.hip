@@ -1,0 +1,1611 @@
+// rmpc_kernels.hip -- batched multiple-shooting interior-point MPC solver for
+// MI355X (gfx950).  Replaces the FORCES Pro generated solver behind
+// robotmpcs.planner.mpcPlanner.MPCPlanner.solve() (mpcPlanner.py:262).
+//
+// One solve = pack, then passes of three kernels until every instance has
+// stopped, then unpack:
+//
+//   k_sweep   one lane per (instance, stage): forms the trial point
+//             z + alpha dz (t, lambda, nu likewise), evaluates dynamics, cost,
+//             inequality rows and their Jacobians there, condenses the barrier
+//             terms into the stage Hessian / gradient blocks and writes the
+//             merit and KKT partial sums of the stage.             [HBM bound]
+//   k_riccati one lane per instance: reduces the stage partials, runs the
+//             Armijo test on the l1 merit, updates the barrier parameter,
+//             checks convergence and runs the block-tridiagonal Riccati
+//             recursion (backward, forward, costates).   [latency / HBM bound]
+//   k_step    one lane per (instance, stage): slack and multiplier steps,
+//             fraction-to-the-boundary partial minima, merit slope partials.
+//                                                                  [HBM bound]
+//
+// Data layout: every array is [slot][stage][instance] with the instance index
+// contiguous (batch-minor structure of arrays), so a wavefront's 64 lanes read
+// 512 contiguous bytes per slot.  Iterates are double buffered per instance
+// (cur / cur^1): a trial point is written once and accepted by flipping a bit.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rmpc_model.hpp"
+
+namespace rmpc {
+
+// solver constants (identical in oracle/rmpc_oracle.c)
+constexpr double kTMin = 1e-2;
+constexpr double kTau = 0.995;
+constexpr int kLsMax = 25;
+constexpr double kArmijo = 1e-4;
+constexpr double kMuDiverged = 1e12;
+
+enum Status : int { ST_ACTIVE = 100 };
+
+enum Part : int { P_F = 0, P_TH, P_LOGS, P_RSTAT, P_REQ, P_RINEQ, P_RCOMP, P_SUMC, P_MINC, P_BAD, P_COUNT };
+
+// Device workspace (all pointers into one allocation).
+struct Ws {
+  int N, Bp;
+  double *p;                      // [npar][N][Bp]
+  double *z[2], *t[2], *lam[2], *nu[2];
+  double *dz, *dtt, *dlam, *nunew;
+  double *Qqq, *Dg, *cs, *q0, *q1, *gfa, *grow, *Jq, *rc, *A5, *B5;
+  double *Kg, *kff;
+  double *part;                   // [P_COUNT][N][Bp]
+  double *ap, *ad, *gphi;         // [N][Bp]
+  // per instance [Bp]
+  double *mu, *rho, *phi0, *Dd, *fcur, *thcur, *logcur;
+  double *res_stat, *res_eq, *res_ineq, *res_comp, *obj;
+  int *status, *iters, *ls, *cur, *newstep;
+  int *active_hist;               // [max_passes]
+};
+
+#define IDX(slot, k, b) (((size_t)(slot) * W.N + (size_t)(k)) * W.Bp + (size_t)(b))
+
+// ===========================================================================
+// pack / unpack: instance-major ABI layout <-> batch-minor SoA (LDS transpose)
+// ===========================================================================
+// in[b][c], c = k*inner + j  ->  out[(j*N + k)*Bp + b]
+__global__ __launch_bounds__(256) void k_pack(const double *__restrict__ in, double *__restrict__ out, int B,
+                                              int C, int inner, int N, int Bp) {
+  __shared__ double tile[64][65];
+  const int b0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    int b = b0 + r, c = c0 + tx;
+    tile[r][tx] = (b < B && c < C) ? in[(size_t)b * C + c] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    int c = c0 + r, b = b0 + tx;
+    if (c < C && b < B) {
+      int k = c / inner, j = c - k * inner;
+      out[((size_t)j * N + k) * Bp + b] = tile[tx][r];
+    }
+  }
+}
+
+// stage-0 state := xinit (mpcModel.py:108 xinitidx), per-instance state reset
+__global__ __launch_bounds__(256) void k_init(Ws W, const double *__restrict__ xinit, int B, int nx, double mu0) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  for (int j = 0; j < nx; j++) W.z[0][IDX(j, 0, b)] = xinit[(size_t)b * nx + j];
+  W.status[b] = ST_ACTIVE;
+  W.iters[b] = 0;
+  W.ls[b] = 0;
+  W.cur[b] = 0;
+  W.newstep[b] = 0;
+  W.mu[b] = mu0;
+  W.rho[b] = 0.0;
+  W.phi0[b] = 0.0;
+  W.Dd[b] = 0.0;
+  W.fcur[b] = 0.0;
+  W.thcur[b] = 0.0;
+  W.logcur[b] = 0.0;
+  W.res_stat[b] = 0.0; W.res_eq[b] = 0.0; W.res_ineq[b] = 0.0; W.res_comp[b] = 0.0; W.obj[b] = 0.0;
+}
+
+// z (current buffer of each instance) -> z_out[b][k][v]; stats
+__global__ __launch_bounds__(256) void k_unpack(Ws W, double *__restrict__ zout, int *__restrict__ exitflag,
+                                                int *__restrict__ iters, double *__restrict__ kkt,
+                                                double *__restrict__ obj, int B, int nv) {
+  __shared__ double tile[64][65];
+  const int N = W.N;
+  const int C = N * nv;
+  const int b0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    int c = c0 + r, b = b0 + tx;
+    double v = 0.0;
+    if (c < C && b < B) {
+      int k = c / nv, j = c - k * nv;
+      v = W.z[W.cur[b]][IDX(j, k, b)];
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    int b = b0 + r, c = c0 + tx;
+    if (b < B && c < C) zout[(size_t)b * C + c] = tile[tx][r];
+  }
+  if (blockIdx.y == 0 && threadIdx.x < 64) {
+    int b = b0 + threadIdx.x;
+    if (b < B) {
+      int st = W.status[b];
+      exitflag[b] = (st == ST_ACTIVE) ? 0 : st;
+      iters[b] = W.iters[b];
+      double r = fmax(fmax(W.res_stat[b], W.res_eq[b]), fmax(W.res_ineq[b], W.res_comp[b]));
+      kkt[b] = r;
+      obj[b] = W.obj[b];
+    }
+  }
+}
+
+// ===========================================================================
+// k_sweep: stage-parallel function / Jacobian evaluation + condensing
+// ===========================================================================
+template <class C>
+__global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, const int B, const int first) {
+  constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int b = gid % W.Bp;
+  const int k = gid / W.Bp;  // uniform per wavefront (Bp % 64 == 0)
+  if (b >= B || k >= M.N) return;
+  if (W.status[b] != ST_ACTIVE) return;
+  const int N = M.N;
+  const int cur = W.cur[b], nxt = cur ^ 1;
+  const double *zc = W.z[cur], *tc = W.t[cur], *lc = W.lam[cur], *nc = W.nu[cur];
+  double *zn = W.z[nxt], *tn = W.t[nxt], *ln = W.lam[nxt], *nn = W.nu[nxt];
+  const double mu = W.mu[b];
+
+  // ---- step lengths of this trial --------------------------------------
+  double alpha = 0.0, adual = 0.0;
+  if (!first) {
+    double a0 = 1.0, d0 = 1.0;
+    for (int kk = 0; kk < N; kk++) {
+      a0 = fmin(a0, W.ap[(size_t)kk * W.Bp + b]);
+      d0 = fmin(d0, W.ad[(size_t)kk * W.Bp + b]);
+    }
+    alpha = ldexp(a0, -W.ls[b]);
+    adual = d0;
+  }
+
+  // ---- trial stage vector ------------------------------------------------
+  double z[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    double v = zc[IDX(j, k, b)];
+    if (!first) v += alpha * W.dz[IDX(j, k, b)];
+    z[j] = v;
+    zn[IDX(j, k, b)] = v;
+  }
+  // multipliers of the dynamics: nu_k (k >= 1), nu_{k+1} (k < N-1)
+  double nuk[NX], nun[NX];
+#pragma unroll
+  for (int j = 0; j < NX; j++) {
+    double v = 0.0;
+    if (!first && k >= 1) {
+      const double o = nc[IDX(j, k, b)];
+      v = o + alpha * (W.nunew[IDX(j, k, b)] - o);
+    }
+    nuk[j] = v;
+    nn[IDX(j, k, b)] = v;
+    double w = 0.0;
+    if (!first && k < N - 1) {
+      const double o = nc[IDX(j, k + 1, b)];
+      w = o + alpha * (W.nunew[IDX(j, k + 1, b)] - o);
+    }
+    nun[j] = w;
+  }
+
+  auto P = [&](int off) __attribute__((always_inline)) -> double { return W.p[IDX(off, k, b)]; };
+
+  // ---- accumulators --------------------------------------------------------
+  double gf[NV], q0[NV], q1[NV], rs[NV], Dg[NV], cs[NV];
+  double Qqq[NQ][NQ];
+#pragma unroll
+  for (int j = 0; j < NV; j++) { gf[j] = 0; q0[j] = 0; q1[j] = 0; rs[j] = 0; Dg[j] = 0; cs[j] = 0; }
+#pragma unroll
+  for (int a = 0; a < NQ; a++)
+#pragma unroll
+    for (int c = 0; c < NQ; c++) Qqq[a][c] = 0;
+  double f = 0.0;
+  int bad = 0;
+
+  // ---- kinematics ------------------------------------------------------------
+  Kin<C> kin;
+  {
+    double q[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; j++) q[j] = z[j];
+    kin.compute(M, q);
+  }
+
+  // ---- GoalReaching (goal_reaching.py:19-33), Gauss-Newton Hessian -----------
+  if (M.has_goal) {
+    const Vec3 pe = kin.pos(M, M.end_frame);
+    Vec3 J[NQ];
+    kin.jac(M, M.end_frame, pe, J);
+    const double e0 = pe.x - P(M.off_goal), e1 = pe.y - P(M.off_goal + 1), e2 = pe.z - P(M.off_goal + 2);
+    const double w0 = P(M.off_wgoal), w1 = P(M.off_wgoal + 1), w2 = P(M.off_wgoal + 2);
+    f += w0 * e0 * e0 + w1 * e1 * e1 + w2 * e2 * e2;
+#pragma unroll
+    for (int a = 0; a < NQ; a++) {
+      gf[a] += 2.0 * (w0 * e0 * J[a].x + w1 * e1 * J[a].y + w2 * e2 * J[a].z);
+#pragma unroll
+      for (int c = a; c < NQ; c++)
+        Qqq[a][c] += 2.0 * (w0 * J[a].x * J[c].x + w1 * J[a].y * J[c].y + w2 * J[a].z * J[c].z);
+    }
+  }
+  // ---- control effort and slack penalty (ObjectiveManager.py:28-42) ----------
+#pragma unroll
+  for (int j = 0; j < NU; j++) {
+    const double wu = P(M.off_wu + j), u = z[NX + NS + j];
+    f += wu * u * u;
+    gf[NX + NS + j] += 2.0 * wu * u;
+    Dg[NX + NS + j] += 2.0 * wu;
+  }
+  double sl = 0.0;
+  if constexpr (NS > 0) {
+    const double ws = P(M.off_ws);
+    sl = z[NX];
+    f += ws * sl * sl;
+    gf[NX] += 2.0 * ws * sl;
+    Dg[NX] += 2.0 * ws;
+  }
+
+  // ---- inequality rows ---------------------------------------------------------
+  double theta = 0.0, logsum = 0.0, rineq = 0.0, rcomp = 0.0, sumc = 0.0, minc = 1e300;
+  const double rbody = (M.off_r_body >= 0) ? P(M.off_r_body) : 0.0;
+
+  // one row with value g (slack already added), gradient: gq over q (FK rows) or a
+  // single variable (var, sg); slack coupling when soft.
+  auto row_update = [&](int i, double g, bool is_fk, const double (&gq)[NQ], int var, double sg, bool soft) __attribute__((always_inline)) {
+    double tv, lv;
+    if (first) {
+      tv = g > kTMin ? g : kTMin;
+      lv = mu / tv;
+    } else {
+      tv = tc[IDX(i, k, b)] + alpha * W.dtt[IDX(i, k, b)];
+      lv = lc[IDX(i, k, b)] + adual * W.dlam[IDX(i, k, b)];
+    }
+    tn[IDX(i, k, b)] = tv;
+    ln[IDX(i, k, b)] = lv;
+    const double rg = g - tv;
+    theta += fabs(rg);
+    logsum += log(tv);
+    rineq = fmax(rineq, fabs(rg));
+    const double cmp = tv * lv;
+    rcomp = fmax(rcomp, cmp);
+    sumc += cmp;
+    minc = fmin(minc, cmp);
+    const double sig = lv / tv, ca = lv * rg / tv, cb = 1.0 / tv;
+    if (is_fk) {
+#pragma unroll
+      for (int a = 0; a < NQ; a++) {
+        q0[a] += gq[a] * ca;
+        q1[a] += gq[a] * cb;
+        rs[a] -= gq[a] * lv;
+#pragma unroll
+        for (int c = a; c < NQ; c++) Qqq[a][c] += sig * gq[a] * gq[c];
+        if constexpr (NS > 0) { if (soft) cs[a] += sig * gq[a]; }
+      }
+    } else {
+      // single variable: statically indexed update through an unrolled select
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        if (j == var) {
+          q0[j] += sg * ca;
+          q1[j] += sg * cb;
+          rs[j] -= sg * lv;
+          if (j < NQ) {
+#pragma unroll
+            for (int a = 0; a < NQ; a++) if (a == j) Qqq[a][a] += sig;
+          } else {
+            Dg[j] += sig;
+          }
+          if constexpr (NS > 0) { if (soft) cs[j] += sig * sg; }
+        }
+      }
+    }
+    if constexpr (NS > 0) {
+      if (soft) {
+        q0[NX] += ca;
+        q1[NX] += cb;
+        rs[NX] -= lv;
+        Dg[NX] += sig;
+      }
+    }
+  };
+
+  // inverse-barrier objective on the first row of a module (constraint_avoidance.py:22-31)
+  auto avoid_update = [&](int mi, double h, bool is_fk, const double (&gq)[NQ], int var, double sg) __attribute__((always_inline)) {
+    const double wi = P(M.off_wconstr + mi);
+    if (wi == 0.0) return;
+    const double cN = (double)M.N * wi;
+    if (!(h > 0.0)) bad = 1;
+    f += cN / h;
+    const double c1 = -cN / (h * h), c2 = 2.0 * cN / (h * h * h);
+    if (is_fk) {
+#pragma unroll
+      for (int a = 0; a < NQ; a++) {
+        gf[a] += c1 * gq[a];
+#pragma unroll
+        for (int c = a; c < NQ; c++) Qqq[a][c] += c2 * gq[a] * gq[c];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        if (j == var) {
+          gf[j] += c1 * sg;
+          if (j < NQ) {
+#pragma unroll
+            for (int a = 0; a < NQ; a++) if (a == j) Qqq[a][a] += c2;
+          } else {
+            Dg[j] += c2;
+          }
+        }
+      }
+    }
+  };
+
+  for (int i = 0; i < M.nh; i++) {
+    const int kind = M.row_kind[i];
+    const int ra = M.row_a[i], rb = M.row_b[i];
+    const int mi = M.row_mod[i];
+    const bool firstrow = M.has_avoid && (i == M.mod_row0[mi]);
+    double gq[NQ];
+#pragma unroll
+    for (int a = 0; a < NQ; a++) gq[a] = 0.0;
+    double h = 0.0;
+    int var = -1;
+    double sg = 0.0;
+    bool is_fk = true;
+    if (kind == ROW_RADIAL) {
+      // ||fk_l(q) - c_i|| - r_i - r_body (mpcBase.py:82-101)
+      const Vec3 pl = kin.pos(M, ra);
+      Vec3 J[NQ];
+      kin.jac(M, ra, pl, J);
+      const int o = M.off_obst + 4 * rb;
+      const Vec3 dv = {pl.x - P(o), pl.y - P(o + 1), pl.z - P(o + 2)};
+      const double dist = sqrt(dot(dv, dv));
+      h = dist - P(o + 3) - rbody;
+      const double inv = 1.0 / dist;
+#pragma unroll
+      for (int a = 0; a < NQ; a++) gq[a] = dot(dv, J[a]) * inv;
+    } else if (kind == ROW_LINEAR) {
+      // |a.fk_l(q) + d| / ||a|| - r_body (LinearConstraints.py:25-40, utils.py:48-52)
+      const Vec3 pl = kin.pos(M, ra);
+      Vec3 J[NQ];
+      kin.jac(M, ra, pl, J);
+      const int o = M.off_lin + 4 * rb;
+      const Vec3 av = {P(o), P(o + 1), P(o + 2)};
+      const double nrm = sqrt(dot(av, av));
+      const double sd = dot(av, pl) + P(o + 3);
+      const double sgn = sd < 0 ? -1.0 : 1.0;
+      h = fabs(sd) / nrm - rbody;
+#pragma unroll
+      for (int a = 0; a < NQ; a++) gq[a] = sgn * dot(av, J[a]) / nrm;
+    } else if (kind == ROW_SELF) {
+      // ||fk_a(q) - fk_b(q)|| - 2 r_body (SelfCollisionAvoidanceConstraints.py:19-27)
+      const Vec3 pa = kin.pos(M, ra), pb = kin.pos(M, rb);
+      Vec3 Ja[NQ], Jb[NQ];
+      kin.jac(M, ra, pa, Ja);
+      kin.jac(M, rb, pb, Jb);
+      const Vec3 dv = pa - pb;
+      const double dist = sqrt(dot(dv, dv));
+      h = dist - 2.0 * rbody;
+      const double inv = 1.0 / dist;
+#pragma unroll
+      for (int a = 0; a < NQ; a++) gq[a] = dot(dv, Ja[a] - Jb[a]) * inv;
+    } else {
+      // joint / velocity / input limits: sg * (z_var - limit)
+      is_fk = false;
+      var = ra;
+      sg = (double)rb;
+      double zv = 0.0;
+#pragma unroll
+      for (int j = 0; j < NV; j++) if (j == var) zv = z[j];
+      h = sg * (zv - P(M.row_poff[i]));
+    }
+    if (firstrow) avoid_update(mi, h, is_fk, gq, var, sg);
+    double g = h;
+    if constexpr (NS > 0) g += sl;  // softened rows (intended InequalityManager.py:29-32)
+    W.grow[IDX(i, k, b)] = g;
+    if (is_fk) {
+      const int fi = M.row_fk[i];
+#pragma unroll
+      for (int a = 0; a < NQ; a++) W.Jq[IDX(fi * NQ + a, k, b)] = gq[a];
+    }
+    row_update(i, g, is_fk, gq, var, sg, NS > 0);
+  }
+  // simple bounds (mpcModel.py:91-104): lower rows then upper rows, never softened
+  {
+    double gq[NQ];
+#pragma unroll
+    for (int a = 0; a < NQ; a++) gq[a] = 0.0;
+    int i = M.nh;
+    for (int r = 0; r < M.nlb; r++, i++) {
+      const int var = M.lb_var[r];
+      double zv = 0.0;
+#pragma unroll
+      for (int j = 0; j < NV; j++) if (j == var) zv = z[j];
+      row_update(i, zv - M.lb_val[r], false, gq, var, 1.0, false);
+    }
+    for (int r = 0; r < M.nub; r++, i++) {
+      const int var = M.ub_var[r];
+      double zv = 0.0;
+#pragma unroll
+      for (int j = 0; j < NV; j++) if (j == var) zv = z[j];
+      row_update(i, M.ub_val[r] - zv, false, gq, var, -1.0, false);
+    }
+  }
+
+  // ---- dynamics defect and stationarity -------------------------------------------
+  double req = 0.0;
+#pragma unroll
+  for (int j = 0; j < NV; j++) rs[j] += gf[j];
+  if (k < N - 1) {
+    double xn[NX];
+    if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
+      chain_step<C>(M.dt, z, xn);
+      const double h = M.dt, h2 = 0.5 * M.dt * M.dt;
+      // A^T nu = [nu_q ; dt nu_q + nu_v],  B^T nu = dt^2/2 nu_q + dt nu_v
+#pragma unroll
+      for (int a = 0; a < NQ; a++) {
+        rs[a] += nun[a];
+        rs[NQ + a] += h * nun[a] + nun[NQ + a];
+        rs[NX + NS + a] += h2 * nun[a] + h * nun[NQ + a];
+      }
+    } else {
+      double A5[25], B5[10];
+      diffdrive_step<C>(M.dt, z, xn, A5, B5, true);
+      constexpr int map[5] = {0, 1, 2, 6, 7};
+#pragma unroll
+      for (int i = 0; i < 25; i++) W.A5[IDX(i, k, b)] = A5[i];
+#pragma unroll
+      for (int i = 0; i < 10; i++) W.B5[IDX(i, k, b)] = B5[i];
+      // A = I outside the reduced block
+#pragma unroll
+      for (int j = 3; j < 6; j++) rs[j] += nun[j];
+#pragma unroll
+      for (int c = 0; c < 5; c++) {
+        double acc = 0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) acc += A5[r * 5 + c] * nun[map[r]];
+        rs[map[c]] += acc;
+      }
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        double acc = 0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) acc += B5[r * 2 + c] * nun[map[r]];
+        rs[NX + NS + c] += acc;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NX; j++) {
+      double xk1 = zc[IDX(j, k + 1, b)];
+      if (!first) xk1 += alpha * W.dz[IDX(j, k + 1, b)];
+      const double r = xn[j] - xk1;
+      W.rc[IDX(j, k, b)] = r;
+      req = fmax(req, fabs(r));
+      theta += fabs(r);
+    }
+  }
+  double rstat = 0.0;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    double r = rs[j];
+    if (j < NX) {
+      if (k == 0) continue;  // x_1 is fixed: no stationarity condition
+      r -= nuk[j];
+    }
+    rstat = fmax(rstat, fabs(r));
+  }
+
+  // ---- write the condensed stage blocks ------------------------------------------
+  {
+    int s = 0;
+#pragma unroll
+    for (int a = 0; a < NQ; a++)
+#pragma unroll
+      for (int c = a; c < NQ; c++) W.Qqq[IDX(s++, k, b)] = Qqq[a][c];
+  }
+#pragma unroll
+  for (int j = NQ; j < NV; j++) W.Dg[IDX(j - NQ, k, b)] = Dg[j];
+  if constexpr (NS > 0) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) W.cs[IDX(j, k, b)] = cs[j];
+  }
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    W.q0[IDX(j, k, b)] = gf[j] + q0[j];
+    W.q1[IDX(j, k, b)] = q1[j];
+    W.gfa[IDX(j, k, b)] = gf[j];
+  }
+  if (!isfinite(f) || !isfinite(theta) || !isfinite(logsum)) bad = 1;
+  W.part[IDX(P_F, k, b)] = f;
+  W.part[IDX(P_TH, k, b)] = theta;
+  W.part[IDX(P_LOGS, k, b)] = logsum;
+  W.part[IDX(P_RSTAT, k, b)] = rstat;
+  W.part[IDX(P_REQ, k, b)] = req;
+  W.part[IDX(P_RINEQ, k, b)] = rineq;
+  W.part[IDX(P_RCOMP, k, b)] = rcomp;
+  W.part[IDX(P_SUMC, k, b)] = sumc;
+  W.part[IDX(P_MINC, k, b)] = minc;
+  W.part[IDX(P_BAD, k, b)] = (double)bad;
+}
+
+// ===========================================================================
+// k_riccati: per-instance decisions + block-tridiagonal Riccati recursion
+// ===========================================================================
+template <int NW>
+__device__ __forceinline__ bool chol_inplace(double (&Mx)[NW][NW]) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NW; j++) {
+    double dg = Mx[j][j];
+#pragma unroll
+    for (int l = 0; l < j; l++) dg -= Mx[j][l] * Mx[j][l];
+    if (!(dg > 0.0)) ok = false;
+    dg = sqrt(dg);
+    Mx[j][j] = dg;
+    const double inv = 1.0 / dg;
+#pragma unroll
+    for (int i = j + 1; i < NW; i++) {
+      double s = Mx[i][j];
+#pragma unroll
+      for (int l = 0; l < j; l++) s -= Mx[i][l] * Mx[j][l];
+      Mx[i][j] = s * inv;
+    }
+  }
+  return ok;
+}
+template <int NW>
+__device__ __forceinline__ void chol_solve(const double (&L)[NW][NW], double (&v)[NW]) {
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    double s = v[i];
+#pragma unroll
+    for (int l = 0; l < i; l++) s -= L[i][l] * v[l];
+    v[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = NW - 1; i >= 0; i--) {
+    double s = v[i];
+#pragma unroll
+    for (int l = i + 1; l < NW; l++) s -= L[l][i] * v[l];
+    v[i] = s / L[i][i];
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, const int B, const int first,
+                                                const int pass) {
+  constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV, NW = C::NW;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  if (W.status[b] != ST_ACTIVE) return;
+  const int N = M.N;
+  W.newstep[b] = 0;
+
+  // ---- reduce the stage partials of the trial point (stage order) ---------------
+  double f = 0, th = 0, lgs = 0, rstat = 0, req = 0, rineq = 0, rcomp = 0, sumc = 0, minc = 1e300, badf = 0;
+  for (int k = 0; k < N; k++) {
+    f += W.part[IDX(P_F, k, b)];
+    th += W.part[IDX(P_TH, k, b)];
+    lgs += W.part[IDX(P_LOGS, k, b)];
+    rstat = fmax(rstat, W.part[IDX(P_RSTAT, k, b)]);
+    req = fmax(req, W.part[IDX(P_REQ, k, b)]);
+    rineq = fmax(rineq, W.part[IDX(P_RINEQ, k, b)]);
+    rcomp = fmax(rcomp, W.part[IDX(P_RCOMP, k, b)]);
+    sumc += W.part[IDX(P_SUMC, k, b)];
+    minc = fmin(minc, W.part[IDX(P_MINC, k, b)]);
+    badf += W.part[IDX(P_BAD, k, b)];
+  }
+  double mu = W.mu[b];
+  int status = ST_ACTIVE;
+  int iters = W.iters[b];
+
+  if (first) {
+    if (badf != 0.0) status = -7;  // inverse-barrier row not strictly feasible at the start
+  } else {
+    double gphi = 0.0, a0 = 1.0;
+    for (int k = 0; k < N; k++) {
+      gphi += W.gphi[(size_t)k * W.Bp + b];
+      a0 = fmin(a0, W.ap[(size_t)k * W.Bp + b]);
+    }
+    int ls = W.ls[b];
+    double rho = W.rho[b], phi0 = W.phi0[b], Dd = W.Dd[b];
+    if (ls == 0) {
+      const double thc = W.thcur[b];
+      if (thc > 1e-13) {
+        const double need = gphi / (0.9 * thc);
+        if (rho < need) rho = need + 1.0;
+      }
+      Dd = gphi - rho * thc;
+      phi0 = W.fcur[b] - mu * W.logcur[b] + rho * thc;
+      W.rho[b] = rho;
+      W.phi0[b] = phi0;
+      W.Dd[b] = Dd;
+    }
+    const double alpha = ldexp(a0, -ls);
+    const double phi = f - mu * lgs + rho * th;
+    const bool ok = (badf == 0.0) && (phi <= phi0 + kArmijo * alpha * Dd + 1e-13 * fabs(phi0));
+    if (!ok) {
+      ls++;
+      if (ls > kLsMax) {
+        W.status[b] = -8;  // line search failure; the current iterate is returned
+        return;
+      }
+      W.ls[b] = ls;
+      atomicAdd(&W.active_hist[pass], 1);
+      return;  // next sweep retries with alpha / 2
+    }
+    iters++;
+  }
+  // ---- accept the trial point ------------------------------------------------------
+  if (status == ST_ACTIVE) {
+    W.cur[b] ^= 1;
+    W.ls[b] = 0;
+    W.fcur[b] = f;
+    W.thcur[b] = th;
+    W.logcur[b] = lgs;
+    W.iters[b] = iters;
+    W.res_stat[b] = rstat; W.res_eq[b] = req; W.res_ineq[b] = rineq; W.res_comp[b] = rcomp; W.obj[b] = f;
+    if (!first) {
+      // LOQO-style centrality rule with floors (oracle/rmpc_oracle.c, barrier update)
+      const double cnt = (double)N * (double)M.m;
+      const double avg = sumc / cnt;
+      const double xi = minc / avg;
+      double sg = 0.05 * (1.0 - xi) / xi;
+      if (sg > 2.0) sg = 2.0;
+      sg = 0.1 * sg * sg * sg;
+      if (sg < 0.02) sg = 0.02;
+      if (sg > 0.8) sg = 0.8;
+      mu = sg * avg;
+      if (mu < 0.1 * M.tol_comp) mu = 0.1 * M.tol_comp;
+      W.mu[b] = mu;
+      if (!(mu < kMuDiverged)) status = -7;
+    }
+  }
+  if (status == ST_ACTIVE) {
+    if (!isfinite(rstat) || !isfinite(req) || !isfinite(rineq)) status = -6;
+    else if (rstat <= M.tol_stat && req <= M.tol_eq && rineq <= M.tol_ineq && rcomp <= M.tol_comp) status = 1;
+    else if (iters >= M.max_iter) status = 0;
+  }
+  if (status != ST_ACTIVE) {
+    W.status[b] = status;
+    return;
+  }
+
+  // ---- Riccati backward recursion ------------------------------------------------------
+  double Pm[NX][NX], pv[NX];
+#pragma unroll
+  for (int i = 0; i < NX; i++) {
+    pv[i] = 0;
+#pragma unroll
+    for (int j = 0; j < NX; j++) Pm[i][j] = 0;
+  }
+  bool chol_ok = true;
+  const double h = M.dt, h2 = 0.5 * M.dt * M.dt;
+  for (int k = N - 1; k >= 0; k--) {
+    double Qxx[NX][NX], Qxw[NX][NW], Qww[NW][NW], qx[NX], qw[NW];
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+#pragma unroll
+      for (int j = 0; j < NX; j++) Qxx[i][j] = 0;
+#pragma unroll
+      for (int j = 0; j < NW; j++) Qxw[i][j] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; i++)
+#pragma unroll
+      for (int j = 0; j < NW; j++) Qww[i][j] = 0;
+    {
+      int s = 0;
+#pragma unroll
+      for (int a = 0; a < NQ; a++)
+#pragma unroll
+        for (int c = a; c < NQ; c++) {
+          const double v = W.Qqq[IDX(s++, k, b)];
+          Qxx[a][c] = v;
+          Qxx[c][a] = v;
+        }
+    }
+#pragma unroll
+    for (int j = NQ; j < NX; j++) Qxx[j][j] = W.Dg[IDX(j - NQ, k, b)];
+#pragma unroll
+    for (int j = 0; j < NW; j++) Qww[j][j] = W.Dg[IDX(NX + j - NQ, k, b)];
+    if constexpr (NS > 0) {
+#pragma unroll
+      for (int j = 0; j < NX; j++) Qxw[j][0] = W.cs[IDX(j, k, b)];
+#pragma unroll
+      for (int j = 0; j < NU; j++) {
+        const double v = W.cs[IDX(NX + 1 + j, k, b)];
+        Qww[0][1 + j] = v;
+        Qww[1 + j][0] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NX; j++) qx[j] = W.q0[IDX(j, k, b)] - mu * W.q1[IDX(j, k, b)];
+#pragma unroll
+    for (int j = 0; j < NW; j++) qw[j] = W.q0[IDX(NX + j, k, b)] - mu * W.q1[IDX(NX + j, k, b)];
+
+    if (k < N - 1) {
+      double rc[NX], Pc[NX];
+#pragma unroll
+      for (int j = 0; j < NX; j++) rc[j] = W.rc[IDX(j, k, b)];
+#pragma unroll
+      for (int i = 0; i < NX; i++) {
+        double s = pv[i];
+#pragma unroll
+        for (int l = 0; l < NX; l++) s += Pm[i][l] * rc[l];
+        Pc[i] = s;
+      }
+      if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
+        // A = [I hI; 0 I], B = [h2 I; h I] (u columns).  Blocks of P: 11, 12, 21, 22.
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+#pragma unroll
+          for (int j = 0; j < NQ; j++) {
+            const double p11 = Pm[i][j], p12 = Pm[i][NQ + j], p21 = Pm[NQ + i][j], p22 = Pm[NQ + i][NQ + j];
+            const double pa12 = h * p11 + p12;           // (PA)_12
+            const double pa22 = h * p21 + p22;           // (PA)_22
+            const double pb1 = h2 * p11 + h * p12;       // (PB)_1
+            const double pb2 = h2 * p21 + h * p22;       // (PB)_2
+            Qxx[i][j] += p11;
+            Qxx[i][NQ + j] += pa12;
+            Qxx[NQ + i][j] += h * p11 + p21;
+            Qxx[NQ + i][NQ + j] += h * pa12 + pa22;
+            Qxw[i][NS + j] += pb1;
+            Qxw[NQ + i][NS + j] += h * pb1 + pb2;
+            Qww[NS + i][NS + j] += h2 * pb1 + h * pb2;
+          }
+          qx[i] += Pc[i];
+          qx[NQ + i] += h * Pc[i] + Pc[NQ + i];
+          qw[NS + i] += h2 * Pc[i] + h * Pc[NQ + i];
+        }
+      } else {
+        // dense A (8x8) rebuilt from the reduced 5x5 block, B (8x2)
+        constexpr int map[5] = {0, 1, 2, 6, 7};
+        double A[NX][NX], Bm[NX][NU];
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+#pragma unroll
+          for (int j = 0; j < NX; j++) A[i][j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; j++) Bm[i][j] = 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+#pragma unroll
+          for (int c = 0; c < 5; c++) A[map[r]][map[c]] = W.A5[IDX(r * 5 + c, k, b)];
+#pragma unroll
+          for (int c = 0; c < 2; c++) Bm[map[r]][c] = W.B5[IDX(r * 2 + c, k, b)];
+        }
+        double PA[NX][NX], PB[NX][NU];
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+#pragma unroll
+          for (int j = 0; j < NX; j++) {
+            double s = 0;
+#pragma unroll
+            for (int l = 0; l < NX; l++) s += Pm[i][l] * A[l][j];
+            PA[i][j] = s;
+          }
+#pragma unroll
+          for (int j = 0; j < NU; j++) {
+            double s = 0;
+#pragma unroll
+            for (int l = 0; l < NX; l++) s += Pm[i][l] * Bm[l][j];
+            PB[i][j] = s;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+#pragma unroll
+          for (int j = 0; j < NX; j++) {
+            double s = 0;
+#pragma unroll
+            for (int l = 0; l < NX; l++) s += A[l][i] * PA[l][j];
+            Qxx[i][j] += s;
+          }
+#pragma unroll
+          for (int j = 0; j < NU; j++) {
+            double s = 0;
+#pragma unroll
+            for (int l = 0; l < NX; l++) s += A[l][i] * PB[l][j];
+            Qxw[i][NS + j] += s;
+          }
+          double s = 0;
+#pragma unroll
+          for (int l = 0; l < NX; l++) s += A[l][i] * Pc[l];
+          qx[i] += s;
+        }
+#pragma unroll
+        for (int i = 0; i < NU; i++) {
+#pragma unroll
+          for (int j = 0; j < NU; j++) {
+            double s = 0;
+#pragma unroll
+            for (int l = 0; l < NX; l++) s += Bm[l][i] * PB[l][j];
+            Qww[NS + i][NS + j] += s;
+          }
+          double s = 0;
+#pragma unroll
+          for (int l = 0; l < NX; l++) s += Bm[l][i] * Pc[l];
+          qw[NS + i] += s;
+        }
+      }
+    }
+    // gains
+    if (!chol_inplace<NW>(Qww)) chol_ok = false;
+    double Kx[NW][NX], kf[NW];
+#pragma unroll
+    for (int j = 0; j < NX; j++) {
+      double col[NW];
+#pragma unroll
+      for (int i = 0; i < NW; i++) col[i] = -Qxw[j][i];
+      chol_solve<NW>(Qww, col);
+#pragma unroll
+      for (int i = 0; i < NW; i++) Kx[i][j] = col[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NW; i++) kf[i] = -qw[i];
+    chol_solve<NW>(Qww, kf);
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+      W.kff[IDX(i, k, b)] = kf[i];
+#pragma unroll
+      for (int j = 0; j < NX; j++) W.Kg[IDX(i * NX + j, k, b)] = Kx[i][j];
+    }
+    // cost-to-go
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+#pragma unroll
+      for (int j = 0; j < NX; j++) {
+        double s = Qxx[i][j];
+#pragma unroll
+        for (int l = 0; l < NW; l++) s += Qxw[i][l] * Kx[l][j];
+        Pm[i][j] = s;
+      }
+      double s = qx[i];
+#pragma unroll
+      for (int l = 0; l < NW; l++) s += Qxw[i][l] * kf[l];
+      pv[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; i++)
+#pragma unroll
+      for (int j = i + 1; j < NX; j++) {
+        const double a = 0.5 * (Pm[i][j] + Pm[j][i]);
+        Pm[i][j] = a;
+        Pm[j][i] = a;
+      }
+  }
+  if (!chol_ok) {
+    W.status[b] = -5;
+    return;
+  }
+
+  // ---- forward rollout ---------------------------------------------------------------------
+  double dx[NX];
+#pragma unroll
+  for (int j = 0; j < NX; j++) dx[j] = 0.0;
+  for (int k = 0; k < N; k++) {
+    double dw[NW];
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+      double s = W.kff[IDX(i, k, b)];
+#pragma unroll
+      for (int j = 0; j < NX; j++) s += W.Kg[IDX(i * NX + j, k, b)] * dx[j];
+      dw[i] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < NX; j++) W.dz[IDX(j, k, b)] = dx[j];
+#pragma unroll
+    for (int i = 0; i < NW; i++) W.dz[IDX(NX + i, k, b)] = dw[i];
+    if (k < N - 1) {
+      double dxn[NX];
+      if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+          dxn[i] = W.rc[IDX(i, k, b)] + dx[i] + h * dx[NQ + i] + h2 * dw[NS + i];
+          dxn[NQ + i] = W.rc[IDX(NQ + i, k, b)] + dx[NQ + i] + h * dw[NS + i];
+        }
+      } else {
+        constexpr int map[5] = {0, 1, 2, 6, 7};
+#pragma unroll
+        for (int j = 0; j < NX; j++) dxn[j] = W.rc[IDX(j, k, b)];
+#pragma unroll
+        for (int j = 3; j < 6; j++) dxn[j] += dx[j];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+          double s = 0;
+#pragma unroll
+          for (int c = 0; c < 5; c++) s += W.A5[IDX(r * 5 + c, k, b)] * dx[map[c]];
+#pragma unroll
+          for (int c = 0; c < 2; c++) s += W.B5[IDX(r * 2 + c, k, b)] * dw[NS + c];
+          dxn[map[r]] += s;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NX; j++) dx[j] = dxn[j];
+    }
+  }
+
+  // ---- costates nu+_k = (Q dz)_x + q_x + A^T nu+_{k+1}, backward ------------------------------
+  double nu1[NX];
+#pragma unroll
+  for (int j = 0; j < NX; j++) nu1[j] = 0.0;
+  for (int k = N - 1; k >= 1; k--) {
+    double dzk[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) dzk[j] = W.dz[IDX(j, k, b)];
+    double r[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) r[j] = W.q0[IDX(j, k, b)] - mu * W.q1[IDX(j, k, b)];
+    {
+      int s = 0;
+#pragma unroll
+      for (int a = 0; a < NQ; a++)
+#pragma unroll
+        for (int c = a; c < NQ; c++) {
+          const double v = W.Qqq[IDX(s++, k, b)];
+          r[a] += v * dzk[c];
+          if (c != a) r[c] += v * dzk[a];
+        }
+    }
+#pragma unroll
+    for (int j = NQ; j < NX; j++) r[j] += W.Dg[IDX(j - NQ, k, b)] * dzk[j];
+    if constexpr (NS > 0) {
+#pragma unroll
+      for (int j = 0; j < NX; j++) r[j] += W.cs[IDX(j, k, b)] * dzk[NX];
+    }
+    if (k < N - 1) {
+      if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+          r[i] += nu1[i];
+          r[NQ + i] += h * nu1[i] + nu1[NQ + i];
+        }
+      } else {
+        constexpr int map[5] = {0, 1, 2, 6, 7};
+#pragma unroll
+        for (int j = 3; j < 6; j++) r[j] += nu1[j];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+          double s = 0;
+#pragma unroll
+          for (int rr = 0; rr < 5; rr++) s += W.A5[IDX(rr * 5 + c, k, b)] * nu1[map[rr]];
+          r[map[c]] += s;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NX; j++) {
+      nu1[j] = r[j];
+      W.nunew[IDX(j, k, b)] = r[j];
+    }
+  }
+  W.newstep[b] = 1;
+  atomicAdd(&W.active_hist[pass], 1);
+}
+
+// ===========================================================================
+// k_step: slack / multiplier steps and step-length partials, stage parallel
+// ===========================================================================
+template <class C>
+__global__ __launch_bounds__(256) void k_step(const DevModel M, const Ws W, const int B) {
+  constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NV = C::NV;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int b = gid % W.Bp;
+  const int k = gid / W.Bp;
+  if (b >= B || k >= M.N) return;
+  if (W.status[b] != ST_ACTIVE || !W.newstep[b]) return;
+  const int cur = W.cur[b];
+  const double *zc = W.z[cur], *tc = W.t[cur], *lc = W.lam[cur];
+  const double mu = W.mu[b];
+  double dz[NV], z[NV];
+  double gphi = 0.0;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    dz[j] = W.dz[IDX(j, k, b)];
+    z[j] = zc[IDX(j, k, b)];
+    gphi += W.gfa[IDX(j, k, b)] * dz[j];
+  }
+  double ap = 1.0, ad = 1.0;
+  auto row = [&](int i, double gdz, double g) __attribute__((always_inline)) {
+    const double tv = tc[IDX(i, k, b)], lv = lc[IDX(i, k, b)];
+    const double dt = gdz + (g - tv);
+    const double dl = (mu - tv * lv - lv * dt) / tv;
+    W.dtt[IDX(i, k, b)] = dt;
+    W.dlam[IDX(i, k, b)] = dl;
+    if (dt < 0) ap = fmin(ap, -kTau * tv / dt);
+    if (dl < 0) ad = fmin(ad, -kTau * lv / dl);
+    gphi -= mu * dt / tv;
+  };
+  auto pick = [&](const double (&v)[NV], int var) __attribute__((always_inline)) {
+    double r = 0.0;
+#pragma unroll
+    for (int j = 0; j < NV; j++) if (j == var) r = v[j];
+    return r;
+  };
+  for (int i = 0; i < M.nh; i++) {
+    const double g = W.grow[IDX(i, k, b)];
+    double gdz;
+    if (M.row_kind[i] != ROW_SINGLE) {
+      const int fi = M.row_fk[i];
+      gdz = 0.0;
+#pragma unroll
+      for (int a = 0; a < NQ; a++) gdz += W.Jq[IDX(fi * NQ + a, k, b)] * dz[a];
+    } else {
+      gdz = (double)M.row_b[i] * pick(dz, M.row_a[i]);
+    }
+    if constexpr (NS > 0) gdz += dz[NX];
+    row(i, gdz, g);
+  }
+  int i = M.nh;
+  for (int r = 0; r < M.nlb; r++, i++) {
+    const int var = M.lb_var[r];
+    row(i, pick(dz, var), pick(z, var) - M.lb_val[r]);
+  }
+  for (int r = 0; r < M.nub; r++, i++) {
+    const int var = M.ub_var[r];
+    row(i, -pick(dz, var), M.ub_val[r] - pick(z, var));
+  }
+  W.ap[(size_t)k * W.Bp + b] = ap;
+  W.ad[(size_t)k * W.Bp + b] = ad;
+  W.gphi[(size_t)k * W.Bp + b] = gphi;
+}
+
+}  // namespace rmpc
+
+// ===========================================================================
+// host side: handle, workspace, launch loop, C ABI
+// ===========================================================================
+using namespace rmpc;
+
+static thread_local std::string g_err;
+static int fail(const std::string &m) {
+  g_err = m;
+  return -1;
+}
+#define HIPCHK(x)                                                                         \
+  do {                                                                                    \
+    hipError_t e_ = (x);                                                                  \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(std::string(#x) + ": " + hipGetErrorString(e_));                        \
+  } while (0)
+
+enum KernelId { K_PACK = 0, K_SWEEP, K_RICCATI, K_STEP, K_UNPACK };
+static const char *kKernelNames[RMPC_NUM_KERNELS] = {"k_pack", "k_sweep", "k_riccati", "k_step", "k_unpack"};
+
+struct rmpc_handle {
+  rmpc_desc desc;
+  DevModel M;
+  Ws W;
+  int device = 0;
+  int max_batch = 0;
+  int Bp = 0;
+  int variant = -1;
+  int max_passes = 0;
+  void *ws_base = nullptr;
+  size_t ws_bytes = 0;
+  hipStream_t stream = nullptr;
+  // staging for the host-pointer entry point
+  double *d_xinit = nullptr, *d_x0 = nullptr, *d_params = nullptr, *d_zout = nullptr, *d_kkt = nullptr,
+         *d_obj = nullptr;
+  int *d_exit = nullptr, *d_iters = nullptr;
+  int *h_active = nullptr;  // pinned
+  int last_passes = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> ev_kind;
+  double prof_ms[RMPC_NUM_KERNELS] = {0};
+  int64_t prof_n[RMPC_NUM_KERNELS] = {0};
+  int64_t alg_bytes[RMPC_NUM_KERNELS] = {0};
+};
+
+static int variant_of(const rmpc_desc &d) {
+  // 0..5: (chain n=3, chain n=7, diffdrive) x (ns = 0, 1)
+  int base;
+  if (d.robot == RMPC_ROBOT_CHAIN && d.n == 3) base = 0;
+  else if (d.robot == RMPC_ROBOT_CHAIN && d.n == 7) base = 1;
+  else if (d.robot == RMPC_ROBOT_DIFFDRIVE && d.n == 3) base = 2;
+  else return -1;
+  return base * 2 + (d.ns ? 1 : 0);
+}
+
+static int build_model(const rmpc_desc &d, DevModel &M, std::string &err) {
+  memset(&M, 0, sizeof M);
+  M.robot = d.robot; M.N = d.N; M.n = d.n; M.nx = d.nx; M.nu = d.nu; M.ns = d.ns;
+  M.nv = d.nx + d.ns + d.nu; M.nw = d.ns + d.nu; M.npar = d.npar; M.dt = d.dt;
+  if (d.N < 1 || d.N > 1000) { err = "horizon out of range"; return -1; }
+  if (d.ns != 0 && d.ns != 1) { err = "ns must be 0 or 1"; return -1; }
+  if (d.robot == RMPC_ROBOT_CHAIN) {
+    if (d.nx != 2 * d.n || d.nu != d.n) { err = "holonomic chain needs nx = 2n, nu = n"; return -1; }
+    if (d.n_joints != d.n) { err = "chain with fixed joints between root and end link is not supported"; return -1; }
+    for (int j = 0; j < d.n_joints; j++)
+      if (d.joint_type[j] == RMPC_JOINT_FIXED || d.joint_dof[j] != j) { err = "chain joints must all be actuated, in order"; return -1; }
+  } else if (d.robot == RMPC_ROBOT_DIFFDRIVE) {
+    if (d.n != 3 || d.nx != 8 || d.nu != 2) { err = "diff-drive needs n = 3, nx = 8, nu = 2 (fk.n() == 0)"; return -1; }
+    for (int j = 0; j < d.n_joints; j++)
+      if (d.joint_type[j] != RMPC_JOINT_FIXED) { err = "diff-drive chain must consist of fixed joints"; return -1; }
+  } else { err = "unknown robot kind"; return -1; }
+  if (d.n_joints < 1 || d.n_joints > RMPC_MAX_JOINTS) { err = "n_joints out of range"; return -1; }
+  if (M.nv > RMPC_NV_MAX) { err = "nvar too large"; return -1; }
+  M.n_modules = d.n_modules; M.nobst = d.nobst; M.end_frame = d.end_frame; M.n_joints = d.n_joints;
+  if (d.n_modules < 0 || d.n_modules > RMPC_MAX_MODULES) { err = "n_modules out of range"; return -1; }
+  if (d.n_links < 0 || d.n_links > RMPC_MAX_LINKS || d.n_pairs < 0 || d.n_pairs > RMPC_MAX_PAIRS) { err = "links/pairs out of range"; return -1; }
+  auto frame_ok = [&](int f) { return f >= 0 && f < d.n_joints; };
+  if (!frame_ok(d.end_frame)) { err = "end_frame out of range"; return -1; }
+  for (int j = 0; j < d.n_joints; j++) {
+    M.joint_type[j] = d.joint_type[j];
+    for (int c = 0; c < 3; c++) { M.joint_xyz[j][c] = d.joint_xyz[j][c]; M.joint_axis[j][c] = d.joint_axis[j][c]; }
+    for (int c = 0; c < 9; c++) M.joint_rot[j][c] = d.joint_rot[j][c];
+  }
+  if (d.robot == RMPC_ROBOT_DIFFDRIVE) {
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+    for (int j = 0; j < d.n_joints; j++) {
+      const double *t = d.joint_xyz[j];
+      for (int r = 0; r < 3; r++) o[r] += R[3 * r] * t[0] + R[3 * r + 1] * t[1] + R[3 * r + 2] * t[2];
+      double Rn[9];
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+          Rn[3 * r + c] = R[3 * r] * d.joint_rot[j][c] + R[3 * r + 1] * d.joint_rot[j][3 + c] + R[3 * r + 2] * d.joint_rot[j][6 + c];
+      memcpy(R, Rn, sizeof R);
+      for (int c = 0; c < 3; c++) M.dd_off[j][c] = o[c];
+    }
+  }
+  M.off_r_body = d.off_r_body; M.off_obst = d.off_obst; M.off_lin = d.off_lin; M.off_wu = d.off_wu;
+  M.off_goal = d.off_goal; M.off_wgoal = d.off_wgoal; M.off_wconstr = d.off_wconstr; M.off_ws = d.off_ws;
+  M.has_goal = d.has_goal; M.has_avoid = d.has_avoid;
+  auto off_ok = [&](int off, int len) { return off >= 0 && off + len <= d.npar; };
+  if (!off_ok(d.off_wu, d.nu)) { err = "off_wu"; return -1; }
+  if (d.ns && !off_ok(d.off_ws, 1)) { err = "off_ws"; return -1; }
+  if (d.has_goal && (!off_ok(d.off_goal, 3) || !off_ok(d.off_wgoal, 3))) { err = "goal offsets"; return -1; }
+  if (d.has_avoid && !off_ok(d.off_wconstr, d.n_modules)) { err = "off_wconstr"; return -1; }
+  // general rows in module order
+  int row = 0, nfk = 0;
+  for (int mi = 0; mi < d.n_modules; mi++) {
+    M.mod_kind[mi] = d.module_kind[mi];
+    M.mod_row0[mi] = row;
+    auto push = [&](int kind, int a, int bb, int poff, bool fk) -> bool {
+      if (row >= kMaxRows) return false;
+      M.row_kind[row] = (int8_t)kind; M.row_a[row] = (int8_t)a; M.row_b[row] = (int8_t)bb;
+      M.row_poff[row] = (int16_t)poff; M.row_fk[row] = fk ? (int8_t)nfk++ : (int8_t)-1; M.row_mod[row] = (int8_t)mi;
+      row++;
+      return true;
+    };
+    bool ok = true;
+    switch (d.module_kind[mi]) {
+      case RMPC_MOD_RADIAL:
+        if (!off_ok(d.off_r_body, 1) || !off_ok(d.off_obst, 4 * d.nobst)) { err = "radial offsets"; return -1; }
+        for (int l = 0; l < d.n_links && ok; l++) {
+          if (!frame_ok(d.link_frame[l])) { err = "link frame"; return -1; }
+          for (int i = 0; i < d.nobst && ok; i++) ok = push(ROW_RADIAL, d.link_frame[l], i, 0, true);
+        }
+        break;
+      case RMPC_MOD_LINEAR:
+        if (!off_ok(d.off_r_body, 1) || !off_ok(d.off_lin, 4 * d.nobst)) { err = "linear offsets"; return -1; }
+        for (int l = 0; l < d.n_links && ok; l++) {
+          if (!frame_ok(d.link_frame[l])) { err = "link frame"; return -1; }
+          for (int i = 0; i < d.nobst && ok; i++) ok = push(ROW_LINEAR, d.link_frame[l], i, 0, true);
+        }
+        break;
+      case RMPC_MOD_SELFCOLLISION:
+        if (d.n_pairs > 0 && !off_ok(d.off_r_body, 1)) { err = "self collision offsets"; return -1; }
+        for (int pi = 0; pi < d.n_pairs && ok; pi++) {
+          if (!frame_ok(d.pair_frame[pi][0]) || !frame_ok(d.pair_frame[pi][1])) { err = "pair frame"; return -1; }
+          ok = push(ROW_SELF, d.pair_frame[pi][0], d.pair_frame[pi][1], 0, true);
+        }
+        break;
+      case RMPC_MOD_JOINTLIMIT:
+        if (!off_ok(d.off_lower, d.n) || !off_ok(d.off_upper, d.n)) { err = "joint limit offsets"; return -1; }
+        for (int j = 0; j < d.n && ok; j++) {
+          ok = push(ROW_SINGLE, j, +1, d.off_lower + j, false);
+          ok = ok && push(ROW_SINGLE, j, -1, d.off_upper + j, false);
+        }
+        break;
+      case RMPC_MOD_VELLIMIT:
+        if (!off_ok(d.off_lower_vel, 2) || !off_ok(d.off_upper_vel, 2)) { err = "velocity limit offsets"; return -1; }
+        for (int j = 0; j < 2 && ok; j++) {
+          ok = push(ROW_SINGLE, d.nx - 2 + j, +1, d.off_lower_vel + j, false);
+          ok = ok && push(ROW_SINGLE, d.nx - 2 + j, -1, d.off_upper_vel + j, false);
+        }
+        break;
+      case RMPC_MOD_INPUTLIMIT:
+        if (!off_ok(d.off_lower_u, d.nu) || !off_ok(d.off_upper_u, d.nu)) { err = "input limit offsets"; return -1; }
+        for (int j = 0; j < d.nu && ok; j++) {
+          ok = push(ROW_SINGLE, d.nx + d.ns + j, +1, d.off_lower_u + j, false);
+          ok = ok && push(ROW_SINGLE, d.nx + d.ns + j, -1, d.off_upper_u + j, false);
+        }
+        break;
+      default:
+        err = "unknown constraint module";
+        return -1;
+    }
+    if (!ok) { err = "too many inequality rows"; return -1; }
+    M.mod_rows[mi] = row - M.mod_row0[mi];
+  }
+  M.nh = row; M.nfk = nfk;
+  for (int j = 0; j < M.nv; j++)
+    if (std::isfinite(d.lb[j])) { M.lb_var[M.nlb] = (int8_t)j; M.lb_val[M.nlb] = d.lb[j]; M.nlb++; }
+  for (int j = 0; j < M.nv; j++)
+    if (std::isfinite(d.ub[j])) { M.ub_var[M.nub] = (int8_t)j; M.ub_val[M.nub] = d.ub[j]; M.nub++; }
+  M.m = M.nh + M.nlb + M.nub;
+  M.max_iter = d.max_iter > 0 ? d.max_iter : 200;
+  M.tol_stat = d.tol_stat > 0 ? d.tol_stat : 1e-6;
+  M.tol_eq = d.tol_eq > 0 ? d.tol_eq : 1e-8;
+  M.tol_ineq = d.tol_ineq > 0 ? d.tol_ineq : 1e-8;
+  M.tol_comp = d.tol_comp > 0 ? d.tol_comp : 1e-6;
+  M.mu0 = d.mu0 > 0 ? d.mu0 : 1.0;
+  return 0;
+}
+
+// ---- workspace carving ---------------------------------------------------------------
+struct Carver {
+  char *base;
+  size_t off = 0;
+  explicit Carver(void *b) : base((char *)b) {}
+  template <class T>
+  T *take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T *p = base ? (T *)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W) {
+  Carver c(base);
+  const size_t S = (size_t)M.N * Bp;  // one slot
+  const int nq = M.n, nq2 = nq * (nq + 1) / 2;
+  W.N = M.N; W.Bp = Bp;
+  W.p = c.take<double>(S * M.npar);
+  for (int i = 0; i < 2; i++) {
+    W.z[i] = c.take<double>(S * M.nv);
+    W.t[i] = c.take<double>(S * M.m);
+    W.lam[i] = c.take<double>(S * M.m);
+    W.nu[i] = c.take<double>(S * M.nx);
+  }
+  W.dz = c.take<double>(S * M.nv);
+  W.dtt = c.take<double>(S * M.m);
+  W.dlam = c.take<double>(S * M.m);
+  W.nunew = c.take<double>(S * M.nx);
+  W.Qqq = c.take<double>(S * nq2);
+  W.Dg = c.take<double>(S * (M.nv - nq));
+  W.cs = c.take<double>(S * M.nv);
+  W.q0 = c.take<double>(S * M.nv);
+  W.q1 = c.take<double>(S * M.nv);
+  W.gfa = c.take<double>(S * M.nv);
+  W.grow = c.take<double>(S * (M.nh > 0 ? M.nh : 1));
+  W.Jq = c.take<double>(S * (M.nfk > 0 ? M.nfk * nq : 1));
+  W.rc = c.take<double>(S * M.nx);
+  W.A5 = c.take<double>(S * 25);
+  W.B5 = c.take<double>(S * 10);
+  W.Kg = c.take<double>(S * M.nw * M.nx);
+  W.kff = c.take<double>(S * M.nw);
+  W.part = c.take<double>(S * P_COUNT);
+  W.ap = c.take<double>(S);
+  W.ad = c.take<double>(S);
+  W.gphi = c.take<double>(S);
+  double **per[] = {&W.mu, &W.rho, &W.phi0, &W.Dd, &W.fcur, &W.thcur, &W.logcur,
+                    &W.res_stat, &W.res_eq, &W.res_ineq, &W.res_comp, &W.obj};
+  for (auto pp : per) *pp = c.take<double>(Bp);
+  int **peri[] = {&W.status, &W.iters, &W.ls, &W.cur, &W.newstep};
+  for (auto pp : peri) *pp = c.take<int>(Bp);
+  W.active_hist = c.take<int>(max_passes + 8);
+  return (c.off + 255) & ~(size_t)255;
+}
+
+static int passes_cap(const DevModel &M) { return 4 * M.max_iter + 64; }
+
+// algorithmic bytes moved per launch (DESIGN.md, section "Kernels"); B instances
+static void fill_alg_bytes(rmpc_handle *h, int B) {
+  const DevModel &M = h->M;
+  const int64_t L = (int64_t)B * M.N;  // (instance, stage) lanes
+  const int nq2 = M.n * (M.n + 1) / 2;
+  const int64_t dd = (M.robot == RMPC_ROBOT_DIFFDRIVE) ? 35 : 0;
+  const int64_t sweep_rd = M.nv * 2 + M.m * 4 + M.nx * 4 + M.npar + M.nx * 2 + 2 * M.N;
+  const int64_t sweep_wr = M.nv + 2 * M.m + M.nx + nq2 + (M.nv - M.n) + (M.ns ? M.nv : 0) + 3 * M.nv + M.nh +
+                           M.nfk * M.n + M.nx + dd + P_COUNT;
+  const int64_t ric_rd = P_COUNT + 3 + 2 * (nq2 + (M.nv - M.n) + (M.ns ? M.nv : 0) + 2 * M.nv) + 2 * M.nx + 2 * dd +
+                         (M.nw * M.nx + M.nw) + M.nv;
+  const int64_t ric_wr = (M.nw * M.nx + M.nw) + M.nv + M.nx;
+  const int64_t step_rd = 3 * M.nv + 2 * M.m + M.nh + M.nfk * M.n;
+  const int64_t step_wr = 2 * M.m + 3;
+  h->alg_bytes[K_PACK] = 16 * ((int64_t)B * (M.nx + (int64_t)M.N * (M.nv + M.npar)));
+  h->alg_bytes[K_SWEEP] = 8 * L * (sweep_rd + sweep_wr);
+  h->alg_bytes[K_RICCATI] = 8 * L * (ric_rd + ric_wr);
+  h->alg_bytes[K_STEP] = 8 * L * (step_rd + step_wr);
+  h->alg_bytes[K_UNPACK] = 16 * (int64_t)B * M.N * M.nv;
+}
+
+template <class C>
+static void launch_pass(rmpc_handle *h, int B, int first, int pass, hipStream_t st, int which) {
+  const int lanes = h->Bp * h->M.N;
+  if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->W, B, first);
+  else if (which == K_RICCATI) hipLaunchKernelGGL((k_riccati<C>), dim3((B + 63) / 64), dim3(64), 0, st, h->M, h->W, B, first, pass);
+  else hipLaunchKernelGGL((k_step<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->W, B);
+}
+
+static void launch_variant(rmpc_handle *h, int B, int first, int pass, hipStream_t st, int which) {
+  switch (h->variant) {
+    case 0: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>(h, B, first, pass, st, which); break;
+    case 1: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 3, 1>>(h, B, first, pass, st, which); break;
+    case 2: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 7, 0>>(h, B, first, pass, st, which); break;
+    case 3: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 7, 1>>(h, B, first, pass, st, which); break;
+    case 4: launch_pass<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>(h, B, first, pass, st, which); break;
+    case 5: launch_pass<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>(h, B, first, pass, st, which); break;
+  }
+}
+
+struct ProfScope {
+  rmpc_handle *h;
+  hipStream_t st;
+  int kind;
+  ProfScope(rmpc_handle *h_, hipStream_t st_, int kind_) : h(h_), st(st_), kind(kind_) {
+    if (h->profiling) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      (void)hipEventRecord(e, st);
+      h->ev.push_back(e);
+    }
+  }
+  ~ProfScope() {
+    if (h->profiling) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      (void)hipEventRecord(e, st);
+      h->ev.push_back(e);
+      h->ev_kind.push_back(kind);
+    }
+  }
+};
+
+static void prof_collect(rmpc_handle *h) {
+  for (size_t i = 0; i < h->ev_kind.size(); i++) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]);
+    h->prof_ms[h->ev_kind[i]] += ms;
+    h->prof_n[h->ev_kind[i]]++;
+  }
+  for (auto e : h->ev) (void)hipEventDestroy(e);
+  h->ev.clear();
+  h->ev_kind.clear();
+}
+
+static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
+                        double *d_zout, int *d_exit, int *d_iters, double *d_kkt, double *d_obj, hipStream_t st,
+                        int max_passes_override) {
+  if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
+  const DevModel &M = h->M;
+  HIPCHK(hipSetDevice(h->device));
+  fill_alg_bytes(h, B);
+  HIPCHK(hipMemsetAsync(h->W.active_hist, 0, sizeof(int) * (h->max_passes + 8), st));
+  {
+    ProfScope ps(h, st, K_PACK);
+    dim3 g1((B + 63) / 64, (M.N * M.npar + 63) / 64);
+    hipLaunchKernelGGL(k_pack, g1, dim3(256), 0, st, d_params, h->W.p, B, M.N * M.npar, M.npar, M.N, h->Bp);
+    dim3 g2((B + 63) / 64, (M.N * M.nv + 63) / 64);
+    hipLaunchKernelGGL(k_pack, g2, dim3(256), 0, st, d_x0, h->W.z[0], B, M.N * M.nv, M.nv, M.N, h->Bp);
+    hipLaunchKernelGGL(k_init, dim3((B + 255) / 256), dim3(256), 0, st, h->W, d_xinit, B, M.nx, M.mu0);
+  }
+  const int cap = max_passes_override > 0 ? max_passes_override : h->max_passes;
+  int pass = 0, next_check = 8;
+  for (; pass < cap; pass++) {
+    const int first = pass == 0;
+    { ProfScope ps(h, st, K_SWEEP); launch_variant(h, B, first, pass, st, K_SWEEP); }
+    { ProfScope ps(h, st, K_RICCATI); launch_variant(h, B, first, pass, st, K_RICCATI); }
+    { ProfScope ps(h, st, K_STEP); launch_variant(h, B, first, pass, st, K_STEP); }
+    if (pass + 1 == next_check && max_passes_override <= 0) {
+      HIPCHK(hipMemcpyAsync(h->h_active, h->W.active_hist + pass, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (*h->h_active == 0) { pass++; break; }
+      next_check += 4;
+    }
+  }
+  h->last_passes = pass;
+  {
+    ProfScope ps(h, st, K_UNPACK);
+    dim3 g((B + 63) / 64, (M.N * M.nv + 63) / 64);
+    hipLaunchKernelGGL(k_unpack, g, dim3(256), 0, st, h->W, d_zout, d_exit, d_iters, d_kkt, d_obj, B, M.nv);
+  }
+  HIPCHK(hipGetLastError());
+  if (h->profiling) {
+    HIPCHK(hipStreamSynchronize(st));
+    prof_collect(h);
+  }
+  return 0;
+}
+
+extern "C" {
+
+int rmpc_version(void) { return RMPC_VERSION; }
+const char *rmpc_last_error(void) { return g_err.c_str(); }
+int rmpc_desc_size(void) { return (int)sizeof(rmpc_desc); }
+const char *rmpc_kernel_name(int idx) { return (idx >= 0 && idx < RMPC_NUM_KERNELS) ? kKernelNames[idx] : ""; }
+
+int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch) {
+  if (!desc || desc->struct_size != (int)sizeof(rmpc_desc) || max_batch < 1) return -1;
+  DevModel M;
+  std::string err;
+  if (build_model(*desc, M, err) != 0) { g_err = err; return -1; }
+  Ws W;
+  const int Bp = (max_batch + 63) / 64 * 64;
+  return (int64_t)carve(M, Bp, passes_cap(M), nullptr, W);
+}
+
+int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
+  if (!desc || !out) return fail("null argument");
+  if (desc->struct_size != (int)sizeof(rmpc_desc)) return fail("rmpc_desc size mismatch (ABI version?)");
+  if (max_batch < 1) return fail("max_batch must be >= 1");
+  rmpc_handle *h = new rmpc_handle();
+  h->desc = *desc;
+  std::string err;
+  if (build_model(*desc, h->M, err) != 0) { delete h; return fail("invalid descriptor: " + err); }
+  h->variant = variant_of(*desc);
+  if (h->variant < 0) { delete h; return fail("no kernel variant for this robot (supported: chain n=3, chain n=7, diff-drive n=3)"); }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { delete h; return fail("no HIP device available"); }
+  if (desc->device < 0 || desc->device >= ndev) { delete h; return fail("device ordinal out of range"); }
+  h->device = desc->device;
+  h->max_batch = max_batch;
+  h->Bp = (max_batch + 63) / 64 * 64;
+  h->max_passes = passes_cap(h->M);
+  hipError_t e = hipSetDevice(h->device);
+  if (e != hipSuccess) { delete h; return fail(std::string("hipSetDevice: ") + hipGetErrorString(e)); }
+  Ws tmp;
+  h->ws_bytes = carve(h->M, h->Bp, h->max_passes, nullptr, tmp);
+  e = hipMalloc(&h->ws_base, h->ws_bytes);
+  if (e != hipSuccess) { delete h; return fail(std::string("hipMalloc workspace: ") + hipGetErrorString(e)); }
+  (void)hipMemset(h->ws_base, 0, h->ws_bytes);
+  carve(h->M, h->Bp, h->max_passes, h->ws_base, h->W);
+  (void)hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  (void)hipHostMalloc((void **)&h->h_active, sizeof(int), hipHostMallocDefault);
+  *out = h;
+  return 0;
+}
+
+void rmpc_destroy(rmpc_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void *bufs[] = {h->ws_base, h->d_xinit, h->d_x0, h->d_params, h->d_zout, h->d_kkt, h->d_obj, h->d_exit, h->d_iters};
+  for (void *p : bufs) (void)hipFree(p);
+  if (h->h_active) (void)hipHostFree(h->h_active);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+static int ensure_staging(rmpc_handle *h) {
+  if (h->d_xinit) return 0;
+  const DevModel &M = h->M;
+  const size_t B = h->max_batch;
+  HIPCHK(hipMalloc((void **)&h->d_xinit, sizeof(double) * B * M.nx));
+  HIPCHK(hipMalloc((void **)&h->d_x0, sizeof(double) * B * M.N * M.nv));
+  HIPCHK(hipMalloc((void **)&h->d_params, sizeof(double) * B * M.N * M.npar));
+  HIPCHK(hipMalloc((void **)&h->d_zout, sizeof(double) * B * M.N * M.nv));
+  HIPCHK(hipMalloc((void **)&h->d_kkt, sizeof(double) * B));
+  HIPCHK(hipMalloc((void **)&h->d_obj, sizeof(double) * B));
+  HIPCHK(hipMalloc((void **)&h->d_exit, sizeof(int) * B));
+  HIPCHK(hipMalloc((void **)&h->d_iters, sizeof(int) * B));
+  return 0;
+}
+
+int rmpc_solve_batch(rmpc_handle *h, int B, const double *xinit, const double *x0, const double *params,
+                     double *z_out, int32_t *exitflag, int32_t *iters, double *kkt_res, double *obj) {
+  if (!h || !xinit || !x0 || !params || !z_out || !exitflag) return fail("null argument");
+  if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (ensure_staging(h) != 0) return -1;
+  const DevModel &M = h->M;
+  hipStream_t st = h->stream;
+  HIPCHK(hipMemcpyAsync(h->d_xinit, xinit, sizeof(double) * B * M.nx, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(h->d_x0, x0, sizeof(double) * (size_t)B * M.N * M.nv, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(h->d_params, params, sizeof(double) * (size_t)B * M.N * M.npar, hipMemcpyHostToDevice, st));
+  if (solve_device(h, B, h->d_xinit, h->d_x0, h->d_params, h->d_zout, h->d_exit, h->d_iters, h->d_kkt, h->d_obj, st, 0) != 0)
+    return -1;
+  HIPCHK(hipMemcpyAsync(z_out, h->d_zout, sizeof(double) * (size_t)B * M.N * M.nv, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(exitflag, h->d_exit, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+  if (iters) HIPCHK(hipMemcpyAsync(iters, h->d_iters, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+  if (kkt_res) HIPCHK(hipMemcpyAsync(kkt_res, h->d_kkt, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+  if (obj) HIPCHK(hipMemcpyAsync(obj, h->d_obj, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+int rmpc_solve_batch_device(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
+                            double *d_z_out, int32_t *d_exitflag, int32_t *d_iters, double *d_kkt_res,
+                            double *d_obj, void *stream) {
+  if (!h || !d_xinit || !d_x0 || !d_params || !d_z_out || !d_exitflag || !d_iters || !d_kkt_res || !d_obj)
+    return fail("null argument");
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  return solve_device(h, B, d_xinit, d_x0, d_params, d_z_out, d_exitflag, d_iters, d_kkt_res, d_obj, st, 0);
+}
+
+int rmpc_set_profiling(rmpc_handle *h, int enable) {
+  if (!h) return fail("null handle");
+  h->profiling = enable != 0;
+  for (int i = 0; i < RMPC_NUM_KERNELS; i++) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+  return 0;
+}
+
+int rmpc_get_profile(rmpc_handle *h, double *total_ms, int64_t *launches, int64_t *alg_bytes) {
+  if (!h) return fail("null handle");
+  for (int i = 0; i < RMPC_NUM_KERNELS; i++) {
+    if (total_ms) total_ms[i] = h->prof_ms[i];
+    if (launches) launches[i] = h->prof_n[i];
+    if (alg_bytes) alg_bytes[i] = h->alg_bytes[i];
+  }
+  return 0;
+}
+
+int rmpc_last_passes(rmpc_handle *h) { return h ? h->last_passes : -1; }
+
+int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x0, const double *params,
+                     double *out_Q, double *out_q0, double *out_q1, double *out_rc, double *out_g, double *out_f) {
+  if (!h) return fail("null handle");
+  if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (ensure_staging(h) != 0) return -1;
+  const DevModel &M = h->M;
+  hipStream_t st = h->stream;
+  HIPCHK(hipMemcpyAsync(h->d_xinit, xinit, sizeof(double) * B * M.nx, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(h->d_x0, x0, sizeof(double) * (size_t)B * M.N * M.nv, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(h->d_params, params, sizeof(double) * (size_t)B * M.N * M.npar, hipMemcpyHostToDevice, st));
+  dim3 g1((B + 63) / 64, (M.N * M.npar + 63) / 64);
+  hipLaunchKernelGGL(k_pack, g1, dim3(256), 0, st, h->d_params, h->W.p, B, M.N * M.npar, M.npar, M.N, h->Bp);
+  dim3 g2((B + 63) / 64, (M.N * M.nv + 63) / 64);
+  hipLaunchKernelGGL(k_pack, g2, dim3(256), 0, st, h->d_x0, h->W.z[0], B, M.N * M.nv, M.nv, M.N, h->Bp);
+  hipLaunchKernelGGL(k_init, dim3((B + 255) / 256), dim3(256), 0, st, h->W, h->d_xinit, B, M.nx, M.mu0);
+  launch_variant(h, B, 1, 0, st, K_SWEEP);
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  // gather SoA -> instance-major on the host (debug path, not timed)
+  const size_t S = (size_t)M.N * h->Bp;
+  auto fetch = [&](const double *dptr, size_t slots, std::vector<double> &v) -> int {
+    v.resize(S * slots);
+    HIPCHK(hipMemcpy(v.data(), dptr, sizeof(double) * S * slots, hipMemcpyDeviceToHost));
+    return 0;
+  };
+  std::vector<double> Qqq, Dg, cs, q0, q1, rc, gr, part;
+  const int nq = M.n, nq2 = nq * (nq + 1) / 2, nv = M.nv;
+  if (fetch(h->W.Qqq, nq2, Qqq) || fetch(h->W.Dg, nv - nq, Dg) || fetch(h->W.cs, nv, cs) || fetch(h->W.q0, nv, q0) ||
+      fetch(h->W.q1, nv, q1) || fetch(h->W.rc, M.nx, rc) || fetch(h->W.grow, M.nh > 0 ? M.nh : 1, gr) ||
+      fetch(h->W.part, P_COUNT, part))
+    return -1;
+  auto at = [&](const std::vector<double> &v, int slot, int k, int b) { return v[((size_t)slot * M.N + k) * h->Bp + b]; };
+  for (int b = 0; b < B; b++)
+    for (int k = 0; k < M.N; k++) {
+      const size_t sb = (size_t)b * M.N + k;
+      if (out_Q) {
+        double *Q = out_Q + sb * nv * nv;
+        for (int i = 0; i < nv * nv; i++) Q[i] = 0.0;
+        int s = 0;
+        for (int a = 0; a < nq; a++)
+          for (int c = a; c < nq; c++) { double v = at(Qqq, s++, k, b); Q[a * nv + c] = v; Q[c * nv + a] = v; }
+        for (int j = nq; j < nv; j++) Q[j * nv + j] = at(Dg, j - nq, k, b);
+        if (M.ns)
+          for (int j = 0; j < nv; j++)
+            if (j != M.nx) { double v = at(cs, j, k, b); Q[j * nv + M.nx] = v; Q[M.nx * nv + j] = v; }
+      }
+      for (int j = 0; j < nv; j++) {
+        if (out_q0) out_q0[sb * nv + j] = at(q0, j, k, b);
+        if (out_q1) out_q1[sb * nv + j] = at(q1, j, k, b);
+      }
+      if (out_rc) for (int j = 0; j < M.nx; j++) out_rc[sb * M.nx + j] = (k < M.N - 1) ? at(rc, j, k, b) : 0.0;
+      if (out_g) for (int j = 0; j < M.nh; j++) out_g[sb * M.nh + j] = at(gr, j, k, b);
+      if (out_f) out_f[sb] = at(part, P_F, k, b);
+    }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,283 @@
+// rmpc_model.hpp -- hand-lowered robot models for the MI355X MPC solver.
+//
+// What the reference expresses as CasADi SX graphs and hands to FORCES Pro
+// (robotmpcs/models/*.py) is written here as plain fp64 device functions over
+// compile-time dimensions: forward kinematics with analytic position Jacobians
+// (forwardkinematics' GenericURDFFk call sites mpcBase.py:89-94,
+// goal_reaching.py:22-27, LinearConstraints.py:30-35,
+// SelfCollisionAvoidanceConstraints.py:23-24), the continuous models
+// (mpcModel.py:65-69, diff_drive_mpc_model.py:24-41) and their ERK2 / 5-node
+// discretisation (mpcModel.py:118-120).  Everything a lane touches lives in
+// registers: arrays are statically indexed in fully unrolled loops.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rmpc.h"
+
+namespace rmpc {
+
+constexpr int kMaxRows = 64;  // general inequality rows per stage
+constexpr int kErkNodes = 5;
+
+enum RowKind : int8_t { ROW_RADIAL = 0, ROW_LINEAR = 1, ROW_SELF = 2, ROW_SINGLE = 3 };
+
+// Uniform (kernarg) model: the descriptor plus derived row tables.
+struct DevModel {
+  int robot, N, n, nx, nu, ns, nv, nw, npar;
+  int nh, m, nlb, nub, nfk;
+  double dt;
+  int n_modules;
+  int mod_kind[RMPC_MAX_MODULES], mod_row0[RMPC_MAX_MODULES], mod_rows[RMPC_MAX_MODULES];
+  int nobst;
+  int end_frame;
+  int n_joints;
+  int joint_type[RMPC_MAX_JOINTS];
+  double joint_xyz[RMPC_MAX_JOINTS][3];
+  double joint_rot[RMPC_MAX_JOINTS][9];
+  double joint_axis[RMPC_MAX_JOINTS][3];
+  double dd_off[RMPC_MAX_JOINTS][3];  // diff-drive: frame offset in the base frame
+  int off_r_body, off_obst, off_lin, off_wu, off_goal, off_wgoal, off_wconstr, off_ws;
+  int has_goal, has_avoid;
+  // general rows, YAML module order (InequalityManager.py:25-33)
+  int8_t row_kind[kMaxRows];
+  int8_t row_a[kMaxRows];     // radial/linear: frame; self: frame A; single: variable index
+  int8_t row_b[kMaxRows];     // radial/linear: obstacle; self: frame B; single: sign
+  int16_t row_poff[kMaxRows]; // single: parameter offset of the limit value
+  int8_t row_fk[kMaxRows];    // index among the FK rows, -1 otherwise
+  int8_t row_mod[kMaxRows];   // owning module
+  // finite simple bounds (mpcModel.py:91-104): lower rows first, then upper rows
+  int8_t lb_var[RMPC_NV_MAX], ub_var[RMPC_NV_MAX];
+  double lb_val[RMPC_NV_MAX], ub_val[RMPC_NV_MAX];
+  int max_iter;
+  double tol_stat, tol_eq, tol_ineq, tol_comp, mu0;
+};
+
+struct Vec3 {
+  double x, y, z;
+};
+__device__ __forceinline__ Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ Vec3 cross(Vec3 a, Vec3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// Compile-time configuration of one robot family.
+template <int ROBOT_, int NQ_, int NS_>
+struct Cfg {
+  static constexpr int ROBOT = ROBOT_;
+  static constexpr int NQ = NQ_;
+  static constexpr int NS = NS_;
+  static constexpr int NX = ROBOT_ == RMPC_ROBOT_CHAIN ? 2 * NQ_ : 2 * NQ_ + 2;
+  static constexpr int NU = ROBOT_ == RMPC_ROBOT_CHAIN ? NQ_ : 2;
+  static constexpr int NV = NX + NS_ + NU;
+  static constexpr int NW = NS_ + NU;
+  static constexpr int NQ2 = NQ_ * (NQ_ + 1) / 2;
+  static constexpr int NR = 5;  // reduced diff-drive state (x, y, theta, v, omega)
+};
+
+// ---------------------------------------------------------------------------
+// Kinematics: one pass over the chain, positions of every frame plus what the
+// analytic position Jacobian needs (joint origins and world axes).
+// ---------------------------------------------------------------------------
+template <class C>
+struct Kin {
+  Vec3 fpos[C::ROBOT == RMPC_ROBOT_CHAIN ? C::NQ : 1];
+  Vec3 oj[C::ROBOT == RMPC_ROBOT_CHAIN ? C::NQ : 1];
+  Vec3 aj[C::ROBOT == RMPC_ROBOT_CHAIN ? C::NQ : 1];
+  double c, s, qx, qy;  // diff-drive base pose
+
+  __device__ __forceinline__ void compute(const DevModel &M, const double (&q)[C::NQ]) {
+    if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
+      double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      Vec3 o = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < C::NQ; j++) {
+        const double *t = M.joint_xyz[j];
+        o.x += R[0] * t[0] + R[1] * t[1] + R[2] * t[2];
+        o.y += R[3] * t[0] + R[4] * t[1] + R[5] * t[2];
+        o.z += R[6] * t[0] + R[7] * t[1] + R[8] * t[2];
+        mul33(R, M.joint_rot[j]);
+        const double *ax = M.joint_axis[j];
+        Vec3 a = {R[0] * ax[0] + R[1] * ax[1] + R[2] * ax[2], R[3] * ax[0] + R[4] * ax[1] + R[5] * ax[2],
+                  R[6] * ax[0] + R[7] * ax[1] + R[8] * ax[2]};
+        aj[j] = a;
+        oj[j] = o;
+        if (M.joint_type[j] == RMPC_JOINT_REVOLUTE) {
+          double Rq[9];
+          rodrigues(ax, q[j], Rq);
+          mul33(R, Rq);
+        } else if (M.joint_type[j] == RMPC_JOINT_PRISMATIC) {
+          o.x += a.x * q[j];
+          o.y += a.y * q[j];
+          o.z += a.z * q[j];
+        }
+        fpos[j] = o;
+      }
+    } else {
+      c = cos(q[2]);
+      s = sin(q[2]);
+      qx = q[0];
+      qy = q[1];
+    }
+  }
+
+  // position of frame f (uniform f)
+  __device__ __forceinline__ Vec3 pos(const DevModel &M, int f) const {
+    if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
+      Vec3 r = fpos[0];
+#pragma unroll
+      for (int j = 1; j < C::NQ; j++)
+        if (f == j) r = fpos[j];
+      return r;
+    } else {
+      const double *o = M.dd_off[f];
+      return {qx + c * o[0] - s * o[1], qy + s * o[0] + c * o[1], o[2]};
+    }
+  }
+
+  // d pos(f) / d q_d for every d
+  __device__ __forceinline__ void jac(const DevModel &M, int f, Vec3 pf, Vec3 (&J)[C::NQ]) const {
+    if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
+#pragma unroll
+      for (int d = 0; d < C::NQ; d++) {
+        Vec3 col = {0, 0, 0};
+        if (d <= f) {
+          if (M.joint_type[d] == RMPC_JOINT_REVOLUTE) col = cross(aj[d], pf - oj[d]);
+          else if (M.joint_type[d] == RMPC_JOINT_PRISMATIC) col = aj[d];
+        }
+        J[d] = col;
+      }
+    } else {
+      const double *o = M.dd_off[f];
+      J[0] = {1, 0, 0};
+      J[1] = {0, 1, 0};
+      J[2] = {-s * o[0] - c * o[1], c * o[0] - s * o[1], 0};
+    }
+  }
+
+ private:
+  __device__ __forceinline__ static void mul33(double (&R)[9], const double *Bm) {
+    double r[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) r[3 * i + j] = R[3 * i] * Bm[j] + R[3 * i + 1] * Bm[3 + j] + R[3 * i + 2] * Bm[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = r[i];
+  }
+  __device__ __forceinline__ static void rodrigues(const double *k, double th, double (&R)[9]) {
+    double cs = cos(th), sn = sin(th), v = 1.0 - cs;
+    R[0] = cs + k[0] * k[0] * v;        R[1] = k[0] * k[1] * v - k[2] * sn; R[2] = k[0] * k[2] * v + k[1] * sn;
+    R[3] = k[1] * k[0] * v + k[2] * sn; R[4] = cs + k[1] * k[1] * v;        R[5] = k[1] * k[2] * v - k[0] * sn;
+    R[6] = k[2] * k[0] * v - k[1] * sn; R[7] = k[2] * k[1] * v + k[0] * sn; R[8] = cs + k[2] * k[2] * v;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Discrete dynamics x+ = Phi(x, u): ERK2 (explicit midpoint), 5 nodes.
+// ---------------------------------------------------------------------------
+// Holonomic chain, double integrator (mpcModel.py:65-69).  The Jacobians are
+// the constants A = [I dt I; 0 I], B = [dt^2/2 I; dt I] and are never stored.
+template <class C>
+__device__ __forceinline__ void chain_step(const double dt, const double (&z)[C::NV], double (&xn)[C::NX]) {
+  const double h = dt / kErkNodes;
+#pragma unroll
+  for (int i = 0; i < C::NX; i++) xn[i] = z[i];
+#pragma unroll
+  for (int it = 0; it < kErkNodes; it++) {
+#pragma unroll
+    for (int i = 0; i < C::NQ; i++) {
+      const double u = z[C::NX + C::NS + i];
+      const double vm = xn[C::NQ + i] + 0.5 * h * u;  // midpoint velocity
+      xn[i] += h * vm;
+      xn[C::NQ + i] += h * u;
+    }
+  }
+}
+
+// Diff-drive unicycle (diff_drive_mpc_model.py:24-41) on the reduced state
+// r = (x, y, theta, v, omega) = x[{0,1,2,6,7}]; x[3:6] is carried unchanged.
+// A5 (5x5) and B5 (5x2) are the Jacobians of the reduced map.
+template <class C>
+__device__ __forceinline__ void diffdrive_step(const double dt, const double (&z)[C::NV], double (&xn)[C::NX],
+                                               double (&A5)[25], double (&B5)[10], bool want) {
+  const double h = dt / kErkNodes;
+  double r[5] = {z[0], z[1], z[2], z[6], z[7]};
+  const double u0 = z[C::NX + C::NS], u1 = z[C::NX + C::NS + 1];
+  if (want) {
+#pragma unroll
+    for (int i = 0; i < 25; i++) A5[i] = (i % 6 == 0) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) B5[i] = 0.0;
+  }
+#pragma unroll 1
+  for (int it = 0; it < kErkNodes; it++) {
+    const double c1 = cos(r[2]), s1 = sin(r[2]);
+    const double k1[5] = {c1 * r[3], s1 * r[3], r[4], u0, u1};
+    double rm[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) rm[i] = r[i] + 0.5 * h * k1[i];
+    const double c2 = cos(rm[2]), s2 = sin(rm[2]);
+    const double k2[5] = {c2 * rm[3], s2 * rm[3], rm[4], u0, u1};
+    if (want) {
+      // fx at (r) and (rm): nonzeros (0,2) (0,3) (1,2) (1,3) (2,4)
+      const double f1_02 = -s1 * r[3], f1_03 = c1, f1_12 = c1 * r[3], f1_13 = s1;
+      const double f2_02 = -s2 * rm[3], f2_03 = c2, f2_12 = c2 * rm[3], f2_13 = s2;
+      // M = I + h/2 fx1 ; As = I + h fx2 M ; Bs = h (fx2 (h/2 fu1) + fu2), fu = e3 e0^T + e4 e1^T
+      double As[25], Bs[10];
+#pragma unroll
+      for (int i = 0; i < 25; i++) As[i] = (i % 6 == 0) ? 1.0 : 0.0;
+#pragma unroll
+      for (int i = 0; i < 10; i++) Bs[i] = 0.0;
+      // rows of M that fx2 reads: row 2 = e2 + h/2 * e4 ; row 3 = e3 ; row 4 = e4
+      // row 0 of fx2*M = f2_02 * M[2,:] + f2_03 * M[3,:]
+      As[0 * 5 + 2] += h * f2_02;
+      As[0 * 5 + 4] += h * f2_02 * (0.5 * h);
+      As[0 * 5 + 3] += h * f2_03;
+      As[1 * 5 + 2] += h * f2_12;
+      As[1 * 5 + 4] += h * f2_12 * (0.5 * h);
+      As[1 * 5 + 3] += h * f2_13;
+      As[2 * 5 + 4] += h;
+      (void)f1_02; (void)f1_03; (void)f1_12; (void)f1_13;
+      // M rows 0,1 (which carry fx1) are never read by fx2 (its columns 0,1 are zero),
+      // so fx1 only enters through M[2,4] = h/2.
+      // Bs = h * (fx2 * (h/2) fu1 + fu2): fu1 = fu2 = [e3->u0, e4->u1]
+      Bs[0 * 2 + 0] = h * (f2_03 * 0.5 * h);
+      Bs[1 * 2 + 0] = h * (f2_13 * 0.5 * h);
+      Bs[2 * 2 + 1] = h * (0.5 * h);
+      Bs[3 * 2 + 0] = h;
+      Bs[4 * 2 + 1] = h;
+      double T[25], TB[10];
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          double sacc = 0;
+#pragma unroll
+          for (int l = 0; l < 5; l++) sacc += As[i * 5 + l] * A5[l * 5 + j];
+          T[i * 5 + j] = sacc;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          double sacc = Bs[i * 2 + j];
+#pragma unroll
+          for (int l = 0; l < 5; l++) sacc += As[i * 5 + l] * B5[l * 2 + j];
+          TB[i * 2 + j] = sacc;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 25; i++) A5[i] = T[i];
+#pragma unroll
+      for (int i = 0; i < 10; i++) B5[i] = TB[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) r[i] += h * k2[i];
+  }
+  xn[0] = r[0]; xn[1] = r[1]; xn[2] = r[2];
+  xn[3] = z[3]; xn[4] = z[4]; xn[5] = z[5];
+  xn[6] = r[3]; xn[7] = r[4];
+}
+
+}  // namespace rmpc
