@@ -69,6 +69,14 @@ def load_library(path: str = LIB_PATH):
         return _lib
     if not os.path.exists(path):
         raise RmpcError(f"{path} not found: build the HIP extension first (__graft_entry__.build())")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  Two HIP
+    # runtimes in one process cannot both open the GPU, so when torch is installed
+    # it is imported first: the solver library (NEEDED libamdhip64.so.7) then binds
+    # to the runtime torch already loaded and device pointers / streams are shared.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     L.rmpc_version.restype = C.c_int

@@ -34,7 +34,7 @@
 
 namespace rmpc {
 
-// solver constants (identical in oracle/rmpc_oracle.c)
+// solver constants (DESIGN.md, section "Algorithm")
 constexpr double kTMin = 1e-2;
 constexpr double kTau = 0.995;
 constexpr int kLsMax = 25;
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
     W.iters[b] = iters;
     W.res_stat[b] = rstat; W.res_eq[b] = req; W.res_ineq[b] = rineq; W.res_comp[b] = rcomp; W.obj[b] = f;
     if (!first) {
-      // LOQO-style centrality rule with floors (oracle/rmpc_oracle.c, barrier update)
+      // LOQO-style centrality rule with floors (DESIGN.md, section "Algorithm")
       const double cnt = (double)N * (double)M.m;
       const double avg = sumc / cnt;
       const double xi = minc / avg;

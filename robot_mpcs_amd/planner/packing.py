@@ -96,7 +96,8 @@ class ParamPacker:
         m = self.m
         nbDyn = oa.shape[1] // (3 * m)
         nob = int(self._config.number_obstacles)
-        tgrid = float(self._config.time_step) * np.arange(self.N)  # (N,)
+        dt = float(self._config.time_step)
+        istage = np.arange(self.N, dtype=np.float64)
         p3 = self.p3
         obst_idx = self.idx("obst")
         for j in range(nob):
@@ -107,8 +108,9 @@ class ParamPacker:
                 pos = np.full((self.B, m), -100.0)
                 vel = np.zeros((self.B, m))
                 acc = np.zeros((self.B, m))
-            pred = pos[:, None, :] + vel[:, None, :] * tgrid[None, :, None] \
-                + 0.5 * (tgrid[None, :, None] ** 2) * acc[:, None, :]
+            # same association as the reference: pos + (vel*dt)*i + (0.5*(dt*i)**2)*acc
+            pred = pos[:, None, :] + (vel[:, None, :] * dt) * istage[None, :, None] \
+                + (0.5 * (dt * istage[None, :, None]) ** 2) * acc[:, None, :]
             p3[:, :, obst_idx[j * (m + 1): j * (m + 1) + m]] = pred
             p3[:, :, obst_idx[j * (m + 1) + m]] = self._r
 
