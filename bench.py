@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched MPC solves/sec on MI355X.
+
+A *step* is one pass of the hot path -- one ``rmpc_solve_batch_device`` call --
+over one batch of synthetic input that is already resident in HBM when the
+timed region starts.  Workload at N = 1 GPU: BASELINE.json configs[1]
+(pointRobot, horizon 30, batch 4096, random start / goal + 3 static obstacles);
+with ``--gpus N`` every rank solves its own 4096 instances (weak scaling, no
+data-path collective; one RCCL all-reduce for the max-over-ranks time and one
+gather of solve statistics).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two
+extra objects: ``roofline`` for the dominant kernel (algorithmic bytes per
+launch / average launch duration from HIP events on the solver's stream) and
+``cpu_baseline`` (the CPU oracle port timed on this box's host cores on the
+same inputs; a reported baseline, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+METRIC = "MPC solves/sec (batched) at N=30, pointRobot & panda; 1/2/4/8 MI355X"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2", help="cfg2 (headline), cfg3, cfg4, cfg1")
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: BASELINE batch of the config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not record per-kernel HIP events inside the timed region")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from robot_mpcs_amd import fleet
+    from robot_mpcs_amd._lib import Solver
+    from robot_mpcs_amd.scenarios import DEFAULT_BATCH, make_scenario
+
+    cfg = args.config
+    B = args.batch or DEFAULT_BATCH[cfg]
+    sc = make_scenario(cfg, B=B, seed=1000 + rank)  # every rank owns different instances
+    d = sc.desc
+    N, nv = d["N"], d["nx"] + d["ns"] + d["nu"]
+    solver = Solver(d, max_batch=B, device=local_rank)
+
+    # inputs resident in HBM before the timed region
+    t_xinit = torch.from_numpy(sc.xinit).to(dev)
+    t_x0 = torch.from_numpy(sc.x0).to(dev)
+    t_params = torch.from_numpy(sc.params).to(dev)
+    t_z = torch.empty((B, N, nv), dtype=torch.float64, device=dev)
+    t_exit = torch.empty(B, dtype=torch.int32, device=dev)
+    t_iters = torch.empty(B, dtype=torch.int32, device=dev)
+    t_kkt = torch.empty(B, dtype=torch.float64, device=dev)
+    t_obj = torch.empty(B, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        solver.solve_device(B, t_xinit, t_x0, t_params, t_z, t_exit, t_iters, t_kkt, t_obj,
+                            stream=stream.cuda_stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    solver.set_profiling(not args.no_kernel_events)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = solver.get_profile()
+    solver.set_profiling(False)
+    passes = solver.last_passes()
+
+    dd = dist if world > 1 else None
+    elapsed_max = fleet.max_over_ranks(elapsed, dd, dev)   # RCCL all-reduce(MAX)
+
+    exitflag = t_exit.cpu().numpy()
+    iters = t_iters.cpu().numpy()
+    # RCCL all-gather of six solve statistics per rank (48 B): the only other collective
+    allstats = fleet.gather_stats(fleet.solve_stats(exitflag, iters, t_kkt.cpu().numpy()), dd, dev)
+
+    if rank == 0:
+        total_solves = B * world * args.steps
+        value = total_solves / elapsed_max
+        out = {
+            "metric": METRIC,
+            "value": value,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed_max / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": {"cfg1": "BASELINE configs[0]: pointRobot N=10, 1 instance",
+                             "cfg2": "BASELINE configs[1]: pointRobot N=30, batch=4096 random start/goal + 3 static obstacles",
+                             "cfg3": "BASELINE configs[2]: boxer diff-drive N=30, batch=4096, 5 moving obstacles, slack",
+                             "cfg4": "BASELINE configs[3]: panda 7-DoF N=20, batch=1024, joint limits + sphere obstacle"}[cfg],
+                "batch_per_gpu": B, "horizon": N, "nvar": nv, "npar": d["npar"], "nh": d["nh"],
+                "warm_start": "current_state (cold multipliers, every step solves from scratch)",
+                "tolerances": {k: d["options"][k] for k in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp", "max_iter")},
+                "parallelism": f"{world} x independent shards, no data-path collective",
+            },
+            "solve_stats": dict(fleet.summarize(allstats, B), passes_last_step=passes),
+        }
+        # ---- roofline of the dominant kernel (rank 0's HIP events) -------------------
+        if not args.no_kernel_events:
+            loop = {k: v for k, v in prof.items() if k in ("k_sweep", "k_riccati", "k_step") and v["launches"] > 0}
+            if loop:
+                name = max(loop, key=lambda k: loop[k]["total_ms"])
+                v = loop[name]
+                avg_ms = v["total_ms"] / v["launches"]
+                alg_per_launch = v["total_alg_bytes"] / v["launches"]  # active lanes only, averaged
+                achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9
+                traffic = None
+                tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                if os.path.exists(tfile):
+                    try:
+                        traffic = json.load(open(tfile)).get(cfg, {}).get(name)
+                    except Exception:
+                        traffic = None
+                out["roofline"] = {
+                    "kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": alg_per_launch,
+                    "algorithmic_bytes_full_launch": int(v["full_launch_bytes"]),
+                    "avg_launch_ms": avg_ms, "launches": int(v["launches"]),
+                    "note": "bytes count only lanes still active in each launch; average over all launches of the timed region",
+                    "all_kernels": {k: {"total_ms": round(p["total_ms"], 3), "launches": int(p["launches"]),
+                                        "avg_ms": (p["total_ms"] / p["launches"]) if p["launches"] else None,
+                                        "alg_GBps": (p["total_alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9)
+                                        if p["launches"] and p["total_ms"] > 0 else None}
+                                    for k, p in prof.items()},
+                }
+        # ---- CPU baseline: the oracle port on this box's host cores, same inputs ----
+        if not args.no_cpu_baseline:
+            from oracle.oracle import Oracle
+            cores = os.cpu_count() or 1
+            o = Oracle(d)
+            nb = min(B, 4096)
+            o.solve_batch(sc.xinit[:64], sc.x0[:64], sc.params[:64], nthreads=cores)  # warm the threads
+            tc = time.perf_counter()
+            cpu = o.solve_batch(sc.xinit[:nb], sc.x0[:nb], sc.params[:nb], nthreads=cores)
+            tcpu = time.perf_counter() - tc
+            gz = t_z.cpu().numpy()[:nb]
+            same = bool(np.array_equal(cpu["exitflag"], exitflag[:nb]))
+            conv = cpu["exitflag"] == 1
+            dmax = float(np.abs(gz[conv] - cpu["z"][conv]).max()) if conv.any() else 0.0
+            out["cpu_baseline"] = {
+                "value": nb / tcpu, "unit": "solves/s", "cores": cores, "kind": "port",
+                "sample": f"{nb} instances of the same workload (rank 0's inputs), one pass, OpenMP over instances",
+                "seconds": tcpu, "exitflags_equal_gpu": same, "max_abs_diff_vs_gpu_plan": dmax,
+            }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    solver.close()
+
+
+if __name__ == "__main__":
+    main()

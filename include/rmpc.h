@@ -132,8 +132,12 @@ int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch);
  * kernels: 0 pack, 1 sweep, 2 riccati, 3 step, 4 unpack. */
 #define RMPC_NUM_KERNELS 5
 int rmpc_set_profiling(rmpc_handle *h, int enable);
+/* total_ms / launches: summed HIP-event durations and launch counts per kernel;
+ * total_alg_bytes: algorithmic bytes of those launches, counting only the lanes
+ * that were still active in each launch; full_launch_bytes: algorithmic bytes
+ * of one launch with every lane of a max_batch batch active. */
 int rmpc_get_profile(rmpc_handle *h, double *total_ms, int64_t *launches,
-                     int64_t *algorithmic_bytes_per_launch);
+                     double *total_alg_bytes, int64_t *full_launch_bytes);
 const char *rmpc_kernel_name(int idx);
 /* number of sweep/riccati/step passes of the last solve, and instance-iterations */
 int rmpc_last_passes(rmpc_handle *h);

@@ -95,7 +95,7 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_set_profiling.restype = C.c_int
     L.rmpc_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.rmpc_get_profile.restype = C.c_int
-    L.rmpc_get_profile.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.rmpc_get_profile.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int64), dp, C.POINTER(C.c_int64)]
     L.rmpc_kernel_name.restype = C.c_char_p
     L.rmpc_kernel_name.argtypes = [C.c_int]
     L.rmpc_last_passes.restype = C.c_int
@@ -222,9 +222,11 @@ class Solver:
         self._check(self._L.rmpc_set_profiling(self._h, 1 if enable else 0), "rmpc_set_profiling")
 
     def get_profile(self):
-        ms = (C.c_double * NUM_KERNELS)(); n = (C.c_int64 * NUM_KERNELS)(); by = (C.c_int64 * NUM_KERNELS)()
-        self._check(self._L.rmpc_get_profile(self._h, ms, n, by), "rmpc_get_profile")
-        return {self._L.rmpc_kernel_name(i).decode(): dict(total_ms=ms[i], launches=n[i], alg_bytes_per_launch=by[i])
+        ms = (C.c_double * NUM_KERNELS)(); n = (C.c_int64 * NUM_KERNELS)()
+        by = (C.c_double * NUM_KERNELS)(); full = (C.c_int64 * NUM_KERNELS)()
+        self._check(self._L.rmpc_get_profile(self._h, ms, n, by, full), "rmpc_get_profile")
+        return {self._L.rmpc_kernel_name(i).decode(): dict(total_ms=ms[i], launches=n[i], total_alg_bytes=by[i],
+                                                           full_launch_bytes=full[i])
                 for i in range(NUM_KERNELS)}
 
     def last_passes(self) -> int:

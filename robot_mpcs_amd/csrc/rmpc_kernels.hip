@@ -1105,11 +1105,14 @@ struct rmpc_handle {
   int last_passes = 0;
   // profiling
   bool profiling = false;
-  std::vector<hipEvent_t> ev;
+  std::vector<hipEvent_t> ev;   // pool, reused across solves
+  size_t ev_used = 0;
   std::vector<int> ev_kind;
   double prof_ms[RMPC_NUM_KERNELS] = {0};
   int64_t prof_n[RMPC_NUM_KERNELS] = {0};
-  int64_t alg_bytes[RMPC_NUM_KERNELS] = {0};
+  int64_t lane_bytes[RMPC_NUM_KERNELS] = {0};   // per active lane (pack/unpack: per call)
+  double prof_bytes[RMPC_NUM_KERNELS] = {0};     // accumulated algorithmic bytes of the profiled launches
+  std::vector<int> h_hist;
 };
 
 static int variant_of(const rmpc_desc &d) {
@@ -1307,10 +1310,11 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
 
 static int passes_cap(const DevModel &M) { return 4 * M.max_iter + 64; }
 
-// algorithmic bytes moved per launch (DESIGN.md, section "Kernels"); B instances
-static void fill_alg_bytes(rmpc_handle *h, int B) {
+// Algorithmic bytes (DESIGN.md, section "Kernels"): what one ACTIVE lane must read and
+// write by design.  Sweep / step lanes are (instance, stage) pairs, riccati lanes are
+// instances (bytes already multiplied by N stages).  pack / unpack are per call.
+static void fill_lane_bytes(rmpc_handle *h, int B) {
   const DevModel &M = h->M;
-  const int64_t L = (int64_t)B * M.N;  // (instance, stage) lanes
   const int nq2 = M.n * (M.n + 1) / 2;
   const int64_t dd = (M.robot == RMPC_ROBOT_DIFFDRIVE) ? 35 : 0;
   const int64_t sweep_rd = M.nv * 2 + M.m * 4 + M.nx * 4 + M.npar + M.nx * 2 + 2 * M.N;
@@ -1321,11 +1325,11 @@ static void fill_alg_bytes(rmpc_handle *h, int B) {
   const int64_t ric_wr = (M.nw * M.nx + M.nw) + M.nv + M.nx;
   const int64_t step_rd = 3 * M.nv + 2 * M.m + M.nh + M.nfk * M.n;
   const int64_t step_wr = 2 * M.m + 3;
-  h->alg_bytes[K_PACK] = 16 * ((int64_t)B * (M.nx + (int64_t)M.N * (M.nv + M.npar)));
-  h->alg_bytes[K_SWEEP] = 8 * L * (sweep_rd + sweep_wr);
-  h->alg_bytes[K_RICCATI] = 8 * L * (ric_rd + ric_wr);
-  h->alg_bytes[K_STEP] = 8 * L * (step_rd + step_wr);
-  h->alg_bytes[K_UNPACK] = 16 * (int64_t)B * M.N * M.nv;
+  h->lane_bytes[K_PACK] = 16 * ((int64_t)B * (M.nx + (int64_t)M.N * (M.nv + M.npar)));
+  h->lane_bytes[K_SWEEP] = 8 * (sweep_rd + sweep_wr);
+  h->lane_bytes[K_RICCATI] = 8 * (int64_t)M.N * (ric_rd + ric_wr);
+  h->lane_bytes[K_STEP] = 8 * (step_rd + step_wr);
+  h->lane_bytes[K_UNPACK] = 16 * (int64_t)B * M.N * M.nv;
 }
 
 template <class C>
@@ -1347,24 +1351,25 @@ static void launch_variant(rmpc_handle *h, int B, int first, int pass, hipStream
   }
 }
 
+static hipEvent_t prof_event(rmpc_handle *h) {
+  if (h->ev_used == h->ev.size()) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    h->ev.push_back(e);
+  }
+  return h->ev[h->ev_used++];
+}
+
 struct ProfScope {
   rmpc_handle *h;
   hipStream_t st;
   int kind;
   ProfScope(rmpc_handle *h_, hipStream_t st_, int kind_) : h(h_), st(st_), kind(kind_) {
-    if (h->profiling) {
-      hipEvent_t e;
-      (void)hipEventCreate(&e);
-      (void)hipEventRecord(e, st);
-      h->ev.push_back(e);
-    }
+    if (h->profiling) (void)hipEventRecord(prof_event(h), st);
   }
   ~ProfScope() {
     if (h->profiling) {
-      hipEvent_t e;
-      (void)hipEventCreate(&e);
-      (void)hipEventRecord(e, st);
-      h->ev.push_back(e);
+      (void)hipEventRecord(prof_event(h), st);
       h->ev_kind.push_back(kind);
     }
   }
@@ -1377,8 +1382,7 @@ static void prof_collect(rmpc_handle *h) {
     h->prof_ms[h->ev_kind[i]] += ms;
     h->prof_n[h->ev_kind[i]]++;
   }
-  for (auto e : h->ev) (void)hipEventDestroy(e);
-  h->ev.clear();
+  h->ev_used = 0;
   h->ev_kind.clear();
 }
 
@@ -1388,7 +1392,7 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
   if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
   const DevModel &M = h->M;
   HIPCHK(hipSetDevice(h->device));
-  fill_alg_bytes(h, B);
+  fill_lane_bytes(h, B);
   HIPCHK(hipMemsetAsync(h->W.active_hist, 0, sizeof(int) * (h->max_passes + 8), st));
   {
     ProfScope ps(h, st, K_PACK);
@@ -1420,8 +1424,22 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
   }
   HIPCHK(hipGetLastError());
   if (h->profiling) {
+    // active (instance) lanes per pass: the sweep of pass p works on what was still
+    // active after pass p-1, riccati likewise; step on what riccati p left active.
+    h->h_hist.resize(pass + 1);
+    HIPCHK(hipMemcpyAsync(h->h_hist.data(), h->W.active_hist, sizeof(int) * pass, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     prof_collect(h);
+    double act_in = 0, act_out = 0;
+    for (int p = 0; p < pass; p++) {
+      act_in += (p == 0) ? B : h->h_hist[p - 1];
+      act_out += h->h_hist[p];
+    }
+    h->prof_bytes[K_PACK] += (double)h->lane_bytes[K_PACK];
+    h->prof_bytes[K_UNPACK] += (double)h->lane_bytes[K_UNPACK];
+    h->prof_bytes[K_SWEEP] += act_in * M.N * (double)h->lane_bytes[K_SWEEP];
+    h->prof_bytes[K_RICCATI] += act_in * (double)h->lane_bytes[K_RICCATI];
+    h->prof_bytes[K_STEP] += act_out * M.N * (double)h->lane_bytes[K_STEP];
   }
   return 0;
 }
@@ -1480,6 +1498,7 @@ void rmpc_destroy(rmpc_handle *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void *bufs[] = {h->ws_base, h->d_xinit, h->d_x0, h->d_params, h->d_zout, h->d_kkt, h->d_obj, h->d_exit, h->d_iters};
   for (void *p : bufs) (void)hipFree(p);
+  for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->h_active) (void)hipHostFree(h->h_active);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1534,16 +1553,22 @@ int rmpc_solve_batch_device(rmpc_handle *h, int B, const double *d_xinit, const 
 int rmpc_set_profiling(rmpc_handle *h, int enable) {
   if (!h) return fail("null handle");
   h->profiling = enable != 0;
-  for (int i = 0; i < RMPC_NUM_KERNELS; i++) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+  for (int i = 0; i < RMPC_NUM_KERNELS; i++) { h->prof_ms[i] = 0; h->prof_n[i] = 0; h->prof_bytes[i] = 0; }
   return 0;
 }
 
-int rmpc_get_profile(rmpc_handle *h, double *total_ms, int64_t *launches, int64_t *alg_bytes) {
+int rmpc_get_profile(rmpc_handle *h, double *total_ms, int64_t *launches, double *total_alg_bytes,
+                     int64_t *full_launch_bytes) {
   if (!h) return fail("null handle");
+  const int64_t L = (int64_t)h->max_batch * h->M.N;
   for (int i = 0; i < RMPC_NUM_KERNELS; i++) {
     if (total_ms) total_ms[i] = h->prof_ms[i];
     if (launches) launches[i] = h->prof_n[i];
-    if (alg_bytes) alg_bytes[i] = h->alg_bytes[i];
+    if (total_alg_bytes) total_alg_bytes[i] = h->prof_bytes[i];
+    if (full_launch_bytes)
+      full_launch_bytes[i] = (i == K_SWEEP || i == K_STEP) ? L * h->lane_bytes[i]
+                             : (i == K_RICCATI)            ? (int64_t)h->max_batch * h->lane_bytes[i]
+                                                           : h->lane_bytes[i];
   }
   return 0;
 }
