@@ -26,7 +26,8 @@
  * driven from distinct host threads or processes.
  * Errors: functions return 0 on success, non-zero on API misuse or HIP errors
  * (text via rmpc_last_error()).  Solver outcomes are per instance in exitflag:
- *    1 converged, 0 iteration cap reached (plan still usable),
+ *    1 converged, 2 acceptable (feasible, objective stagnated -- cf. IPOPT's
+ *    acceptable level), 0 iteration cap reached (plans with flag >= 0 are usable),
  *   <0 failure (-5 factorisation, -6 non-finite, -7 infeasible/diverged,
  *      -8 line search) -- the planner only tests the sign (mpcPlanner.py:263,
  *      examples/boxer_example.py:194).
@@ -97,6 +98,8 @@ typedef struct rmpc_desc {
   int32_t max_iter;
   double tol_stat, tol_eq, tol_ineq, tol_comp;
   double mu0;
+  int32_t acc_iters;    /* acceptable termination: consecutive stagnant feasible iterations (0 = off, default 8) */
+  double acc_obj_tol;   /* ... relative objective change (default 1e-8) */
 } rmpc_desc;
 
 typedef struct rmpc_handle rmpc_handle;

@@ -240,6 +240,10 @@ int orc_num_rows(const orc_desc *d, int *nh_out, int *m_out) {
 /* stage evaluation                                                     */
 /* ------------------------------------------------------------------ */
 #define ORC_EVAL_BAD_AVOID (-100) /* an inverse-barrier row has h <= 0 */
+/* second-order terms of the distance rows, filled by orc_eval_stage(want = 1) */
+static __thread double tl_C[ORC_NH_MAX][64];   /* n x n curvature matrix per general row (zero if none) */
+static __thread double tl_cw[ORC_NH_MAX];      /* extra weight from the inverse-barrier objective */
+
 
 int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
                    int want, double *f_out, double *gf, double *H, double *g,
@@ -303,7 +307,7 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
   }
   /* --- inequality modules, YAML order (InequalityManager.py:25-33) --- */
   int row = 0;
-  if (want) memset(Jg, 0, sizeof(double) * MRM * nv);
+  if (want) { memset(Jg, 0, sizeof(double) * MRM * nv); memset(tl_C, 0, sizeof tl_C); memset(tl_cw, 0, sizeof tl_cw); }
   for (int mi = 0; mi < d->n_modules; mi++) {
     const int kind = d->module_kind[mi];
     const int row0 = row;
@@ -318,9 +322,15 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
           double dv[3] = {fpos[fr][0] - ob[0], fpos[fr][1] - ob[1], fpos[fr][2] - ob[2]};
           double dist = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
           g[row] = dist - ob[3] - rb;
-          if (want)
+          if (want) {
             for (int a = 0; a < n; a++)
               Jg[row * nv + a] = (dv[0] * fJ[fr][0 * n + a] + dv[1] * fJ[fr][1 * n + a] + dv[2] * fJ[fr][2 * n + a]) / dist;
+            for (int a = 0; a < n; a++)
+              for (int bb = 0; bb < n; bb++) {
+                double jj = fJ[fr][0 * n + a] * fJ[fr][0 * n + bb] + fJ[fr][1 * n + a] * fJ[fr][1 * n + bb] + fJ[fr][2 * n + a] * fJ[fr][2 * n + bb];
+                tl_C[row][a * n + bb] = (jj - Jg[row * nv + a] * Jg[row * nv + bb]) / dist;
+              }
+          }
           row++;
         }
       }
@@ -352,12 +362,19 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
         double dv[3] = {fpos[fa][0] - fpos[fb][0], fpos[fa][1] - fpos[fb][1], fpos[fa][2] - fpos[fb][2]};
         double dist = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
         g[row] = dist - 2.0 * rb;
-        if (want)
+        if (want) {
           for (int a = 0; a < n; a++) {
             double s3 = 0;
             for (int i = 0; i < 3; i++) s3 += dv[i] * (fJ[fa][i * n + a] - fJ[fb][i * n + a]);
             Jg[row * nv + a] = s3 / dist;
           }
+          for (int a = 0; a < n; a++)
+            for (int bb = 0; bb < n; bb++) {
+              double jj = 0;
+              for (int i = 0; i < 3; i++) jj += (fJ[fa][i * n + a] - fJ[fb][i * n + a]) * (fJ[fa][i * n + bb] - fJ[fb][i * n + bb]);
+              tl_C[row][a * n + bb] = (jj - Jg[row * nv + a] * Jg[row * nv + bb]) / dist;
+            }
+        }
         row++;
       }
     } else if (kind == ORC_MOD_JOINTLIMIT) {
@@ -409,6 +426,7 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
         if (want) {
           const double *jr = Jg + row0 * nv;
           double c1 = -c / (h * h), c2 = 2.0 * c / (h * h * h);
+          tl_cw[row0] = c / (h * h);
           for (int a = 0; a < nv; a++) {
             gf[a] += c1 * jr[a];
             if (jr[a] != 0.0)
@@ -463,6 +481,10 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
 #define ORC_LS_MAX 25      /* max halvings in the line search */
 #define ORC_ARMIJO 1e-4
 #define ORC_MU_DIVERGED 1e12
+#define ORC_CURV_MU 1e-2    /* curvature terms only once the barrier parameter is this small */
+#define ORC_LS_CURV 3       /* trials granted to a step computed with constraint curvature */
+#define ORC_CURV_FAIL_MAX 5 /* consecutive curvature-step failures before latching Gauss-Newton */
+#define ORC_ACC_FEAS 1e-6   /* ... feasibility / complementarity level */
 #define ORC_TRACE_W 8
 
 typedef struct {
@@ -473,6 +495,7 @@ typedef struct {
   double *K, *kff, *P, *pv;
   double *dz, *dtt, *dlam, *nunew;
   double *zt, *tt, *gt, *xnt;
+  double *Cc, *cw;
 } orc_work;
 
 static double *dalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
@@ -492,13 +515,14 @@ static int work_alloc(orc_work *w, const orc_desc *d, int m) {
   w->nunew = dalloc((size_t)N * nx);
   w->zt = dalloc((size_t)N * nv); w->tt = dalloc((size_t)N * m); w->gt = dalloc((size_t)N * MRM);
   w->xnt = dalloc((size_t)N * nx);
+  w->Cc = dalloc((size_t)N * ORC_NH_MAX * 64); w->cw = dalloc((size_t)N * ORC_NH_MAX);
   return 0;
 }
 static void work_free(orc_work *w) {
   free(w->z); free(w->t); free(w->lam); free(w->nu); free(w->f); free(w->gf); free(w->H);
   free(w->g); free(w->Jg); free(w->xn); free(w->A); free(w->Bm); free(w->Q); free(w->qv);
   free(w->rc); free(w->K); free(w->kff); free(w->P); free(w->pv); free(w->dz); free(w->dtt);
-  free(w->dlam); free(w->nunew); free(w->zt); free(w->tt); free(w->gt); free(w->xnt);
+  free(w->dlam); free(w->nunew); free(w->zt); free(w->tt); free(w->gt); free(w->xnt); free(w->Cc); free(w->cw);
 }
 
 /* evaluate every stage with derivatives at w->z; returns 0, or <0 */
@@ -510,6 +534,8 @@ static int eval_all(const orc_desc *d, orc_work *w, const double *params) {
                            w->gf + (size_t)k * nv, w->H + (size_t)k * nv * nv, w->g + (size_t)k * MRM,
                            w->Jg + (size_t)k * MRM * nv, k < N - 1 ? w->xn + (size_t)k * nx : 0,
                            w->A + (size_t)k * nx * nx, w->Bm + (size_t)k * nx * nw);
+    memcpy(w->Cc + (size_t)k * ORC_NH_MAX * 64, tl_C, sizeof tl_C);
+    memcpy(w->cw + (size_t)k * ORC_NH_MAX, tl_cw, sizeof tl_cw);
     if (r == ORC_EVAL_BAD_AVOID) rc = ORC_EVAL_BAD_AVOID;
     else if (r < 0) return r;
   }
@@ -697,6 +723,28 @@ static int trial_merit(const orc_desc *d, orc_work *w, const double *params, dou
   return 0;
 }
 
+
+/* Second-order terms of the distance rows are used when they are the exact
+ * constraint Hessians: holonomic chain, no slack, n <= 3, and every frame a row
+ * refers to moves affinely with q (prismatic joints, or a revolute joint at the
+ * frame itself) -- the point robot.  DESIGN.md, section "Algorithm". */
+static int frame_is_affine(const orc_desc *d, int f) {
+  for (int j = 0; j <= f; j++)
+    if (d->joint_type[j] == ORC_JOINT_REVOLUTE && j != f) return 0;
+  return 1;
+}
+static int model_uses_curvature(const orc_desc *d) {
+  if (d->robot != ORC_ROBOT_CHAIN || d->ns != 0 || d->n > 3) return 0;
+  for (int mi = 0; mi < d->n_modules; mi++) {
+    if (d->module_kind[mi] == ORC_MOD_RADIAL)
+      for (int l = 0; l < d->n_links; l++) if (!frame_is_affine(d, d->link_frame[l])) return 0;
+    if (d->module_kind[mi] == ORC_MOD_SELFCOLLISION)
+      for (int p = 0; p < d->n_pairs; p++)
+        if (!frame_is_affine(d, d->pair_frame[p][0]) || !frame_is_affine(d, d->pair_frame[p][1])) return 0;
+  }
+  return 1;
+}
+
 int orc_solve(const orc_desc *d, const double *xinit, const double *x0, const double *params,
               double *zout, orc_stats *st, double *trace) {
   int nh, m;
@@ -710,6 +758,9 @@ int orc_solve(const orc_desc *d, const double *xinit, const double *x0, const do
   memset(st, 0, sizeof *st);
   double mu = d->mu0, rho = 0.0;
   int exitflag = 0, it = 0;
+  const int curv_ok = model_uses_curvature(d);
+  int gn_sticky = 0, curv_fail = 0, stall = 0;
+  double obj_prev = 0.0;
   int ev = eval_all(d, w, params);
   if (ev != 0) { exitflag = (ev == ORC_EVAL_BAD_AVOID) ? -7 : -10; goto done; }
   for (int k = 0; k < N; k++)
@@ -766,62 +817,99 @@ int orc_solve(const orc_desc *d, const double *xinit, const double *x0, const do
       exitflag = 1;
       break;
     }
+    /* acceptable termination (cf. IPOPT acceptable_iter): feasible, complementary and the
+     * objective has not moved for acc_iters consecutive iterations */
+    if (it >= 1 && res_eq <= ORC_ACC_FEAS && res_ineq <= ORC_ACC_FEAS && res_comp <= ORC_ACC_FEAS &&
+        fabs(obj - obj_prev) <= d->acc_obj_tol * fmax(1.0, fabs(obj)))
+      stall++;
+    else
+      stall = 0;
+    obj_prev = obj;
+    if (d->acc_iters > 0 && stall >= d->acc_iters) { exitflag = 2; break; }
     if (it >= d->max_iter) { exitflag = 0; break; }
-    /* ---- condensed stage QPs ---- */
-    for (int k = 0; k < N; k++) {
-      const double *Jg = w->Jg + (size_t)k * MRM * nv;
-      double *Q = w->Q + (size_t)k * nv * nv, *qv = w->qv + (size_t)k * nv;
-      memcpy(Q, w->H + (size_t)k * nv * nv, sizeof(double) * nv * nv);
-      memcpy(qv, w->gf + (size_t)k * nv, sizeof(double) * nv);
-      for (int i = 0; i < m; i++) {
-        double tv = w->t[(size_t)k * m + i], lv = w->lam[(size_t)k * m + i];
-        double rg = w->g[(size_t)k * MRM + i] - tv;
-        double sig = lv / tv, cq = (mu - lv * rg) / tv;
-        const double *jr = Jg + i * nv;
-        for (int a = 0; a < nv; a++) {
-          if (jr[a] == 0.0) continue;
-          qv[a] -= jr[a] * cq;
-          for (int b = 0; b < nv; b++) Q[a * nv + b] += sig * jr[a] * jr[b];
+    /* ---- step computation: exact constraint curvature first (when the model
+     * qualifies and no fallback is latched), Gauss-Newton blocks otherwise ---- */
+    int use_curv = curv_ok && !gn_sticky && mu <= ORC_CURV_MU;
+    double alpha = 0.0, ad = 1.0;
+    int ls = 0, accepted = 0, fatal = 0;
+    for (;;) {
+      for (int k = 0; k < N; k++) {
+        const double *Jg = w->Jg + (size_t)k * MRM * nv;
+        double *Q = w->Q + (size_t)k * nv * nv, *qv = w->qv + (size_t)k * nv;
+        memcpy(Q, w->H + (size_t)k * nv * nv, sizeof(double) * nv * nv);
+        memcpy(qv, w->gf + (size_t)k * nv, sizeof(double) * nv);
+        for (int i = 0; i < m; i++) {
+          double tv = w->t[(size_t)k * m + i], lv = w->lam[(size_t)k * m + i];
+          double rg = w->g[(size_t)k * MRM + i] - tv;
+          double sig = lv / tv, cq = (mu - lv * rg) / tv;
+          const double *jr = Jg + i * nv;
+          for (int a2 = 0; a2 < nv; a2++) {
+            if (jr[a2] == 0.0) continue;
+            qv[a2] -= jr[a2] * cq;
+            for (int b2 = 0; b2 < nv; b2++) Q[a2 * nv + b2] += sig * jr[a2] * jr[b2];
+          }
+          if (use_curv && i < nh) {
+            /* - (lambda_i + cN/h^2) * grad^2 h_i, distance rows with affine kinematics */
+            const double *Cm = w->Cc + ((size_t)k * ORC_NH_MAX + i) * 64;
+            double wgt = lv + w->cw[(size_t)k * ORC_NH_MAX + i];
+            for (int a2 = 0; a2 < d->n; a2++)
+              for (int b2 = 0; b2 < d->n; b2++) Q[a2 * nv + b2] -= wgt * Cm[a2 * d->n + b2];
+          }
         }
       }
-    }
-    if (riccati(w) != 0) { exitflag = -5; break; }
-    /* ---- slack / multiplier steps, fraction to the boundary ---- */
-    double ap = 1.0, ad = 1.0, gphi = 0.0;
-    for (int k = 0; k < N; k++) {
-      const double *Jg = w->Jg + (size_t)k * MRM * nv, *dz = w->dz + (size_t)k * nv;
-      for (int a = 0; a < nv; a++) gphi += w->gf[(size_t)k * nv + a] * dz[a];
-      for (int i = 0; i < m; i++) {
-        double tv = w->t[(size_t)k * m + i], lv = w->lam[(size_t)k * m + i];
-        double dt = w->g[(size_t)k * MRM + i] - tv;
-        for (int a = 0; a < nv; a++) dt += Jg[i * nv + a] * dz[a];
-        double dl = (mu - tv * lv - lv * dt) / tv;
-        w->dtt[(size_t)k * m + i] = dt;
-        w->dlam[(size_t)k * m + i] = dl;
-        if (dt < 0) { double a = -ORC_TAU * tv / dt; if (a < ap) ap = a; }
-        if (dl < 0) { double a = -ORC_TAU * lv / dl; if (a < ad) ad = a; }
-        gphi -= mu * dt / tv;
+      if (riccati(w) != 0) {
+        if (use_curv) { use_curv = 0; continue; } /* this iteration only */
+        fatal = 1;
+        break;
       }
-    }
-    /* ---- l1 merit, Armijo backtracking ---- */
-    if (theta > 1e-13) {
-      double need = gphi / (0.9 * theta);
-      if (rho < need) rho = need + 1.0;
-    }
-    double D = gphi - rho * theta;
-    double phi0 = obj - mu * logsum + rho * theta;
-    double alpha = ap;
-    int ls = 0, accepted = 0;
-    for (ls = 0; ls <= ORC_LS_MAX; ls++) {
-      for (size_t i = 0; i < (size_t)N * nv; i++) w->zt[i] = w->z[i] + alpha * w->dz[i];
-      for (size_t i = 0; i < (size_t)N * m; i++) w->tt[i] = w->t[i] + alpha * w->dtt[i];
-      double ft, tht, lst;
-      if (trial_merit(d, w, params, mu, &ft, &tht, &lst) == 0) {
-        double phi = ft - mu * lst + rho * tht;
-        if (phi <= phi0 + ORC_ARMIJO * alpha * D + 1e-13 * fabs(phi0)) { accepted = 1; break; }
+      /* ---- slack / multiplier steps, fraction to the boundary ---- */
+      double ap = 1.0, gphi = 0.0;
+      ad = 1.0;
+      for (int k = 0; k < N; k++) {
+        const double *Jg = w->Jg + (size_t)k * MRM * nv, *dz = w->dz + (size_t)k * nv;
+        for (int a2 = 0; a2 < nv; a2++) gphi += w->gf[(size_t)k * nv + a2] * dz[a2];
+        for (int i = 0; i < m; i++) {
+          double tv = w->t[(size_t)k * m + i], lv = w->lam[(size_t)k * m + i];
+          double dt = w->g[(size_t)k * MRM + i] - tv;
+          for (int a2 = 0; a2 < nv; a2++) dt += Jg[i * nv + a2] * dz[a2];
+          double dl = (mu - tv * lv - lv * dt) / tv;
+          w->dtt[(size_t)k * m + i] = dt;
+          w->dlam[(size_t)k * m + i] = dl;
+          if (dt < 0) { double a3 = -ORC_TAU * tv / dt; if (a3 < ap) ap = a3; }
+          if (dl < 0) { double a3 = -ORC_TAU * lv / dl; if (a3 < ad) ad = a3; }
+          gphi -= mu * dt / tv;
+        }
       }
-      alpha *= 0.5;
+      /* ---- l1 merit, Armijo backtracking ---- */
+      if (theta > 1e-13) {
+        double need = gphi / (0.9 * theta);
+        if (rho < need) rho = need + 1.0;
+      }
+      double D = gphi - rho * theta;
+      double phi0 = obj - mu * logsum + rho * theta;
+      alpha = ap;
+      accepted = 0;
+      const int ls_cap = use_curv ? ORC_LS_CURV - 1 : ORC_LS_MAX;
+      for (ls = 0; ls <= ls_cap; ls++) {
+        for (size_t i = 0; i < (size_t)N * nv; i++) w->zt[i] = w->z[i] + alpha * w->dz[i];
+        for (size_t i = 0; i < (size_t)N * m; i++) w->tt[i] = w->t[i] + alpha * w->dtt[i];
+        double ft, tht, lst;
+        if (trial_merit(d, w, params, mu, &ft, &tht, &lst) == 0) {
+          double phi = ft - mu * lst + rho * tht;
+          if (phi <= phi0 + ORC_ARMIJO * alpha * D + 1e-13 * fabs(phi0)) { accepted = 1; break; }
+        }
+        alpha *= 0.5;
+      }
+      if (!accepted && use_curv) {
+        /* Gauss-Newton fallback for this iteration; latched after repeated failures */
+        if (++curv_fail >= ORC_CURV_FAIL_MAX) gn_sticky = 1;
+        use_curv = 0;
+        continue;
+      }
+      if (accepted && use_curv) curv_fail = 0;
+      break;
     }
+    if (fatal) { exitflag = -5; break; }
     if (!accepted) { exitflag = -8; break; } /* line search failure */
     if (trace) { trace[(size_t)it * ORC_TRACE_W + 5] = alpha; trace[(size_t)it * ORC_TRACE_W + 7] = ls; }
     memcpy(w->z, w->zt, sizeof(double) * N * nv);

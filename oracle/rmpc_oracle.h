@@ -94,6 +94,8 @@ typedef struct orc_desc {
   int32_t max_iter;
   double tol_stat, tol_eq, tol_ineq, tol_comp;
   double mu0;
+  int32_t acc_iters;
+  double acc_obj_tol;
 } orc_desc;
 
 /* Per-stage model evaluation (dense).  All matrices row-major.
@@ -112,7 +114,7 @@ int orc_num_rows(const orc_desc *d, int *nh, int *m);
 int orc_fk(const orc_desc *d, const double *q, int frame, double *pos, double *Jp);
 
 typedef struct orc_stats {
-  int32_t exitflag; /* 1 converged, 0 iteration cap, <0 failure */
+  int32_t exitflag; /* 1 converged, 2 acceptable (objective stagnated at a feasible point), 0 iteration cap, <0 failure */
   int32_t iters;
   double res_stat, res_eq, res_ineq, res_comp;
   double obj;

@@ -26,6 +26,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,6 +41,10 @@ constexpr double kTau = 0.995;
 constexpr int kLsMax = 25;
 constexpr double kArmijo = 1e-4;
 constexpr double kMuDiverged = 1e12;
+constexpr double kCurvMu = 1e-2; // curvature terms only once the barrier parameter is this small
+constexpr int kLsCurv = 3;        // trials granted to a step computed with constraint curvature
+constexpr int kCurvFailMax = 5;   // consecutive curvature-step failures before Gauss-Newton is latched
+constexpr double kAccFeas = 1e-6; // acceptable termination: feasibility / complementarity level
 
 enum Status : int { ST_ACTIVE = 100 };
 
@@ -51,14 +56,15 @@ struct Ws {
   double *p;                      // [npar][N][Bp]
   double *z[2], *t[2], *lam[2], *nu[2];
   double *dz, *dtt, *dlam, *nunew;
-  double *Qqq, *Dg, *cs, *q0, *q1, *gfa, *grow, *Jq, *rc, *A5, *B5;
-  double *Kg, *kff;
+  double *Qqq, *Cqq, *Dg, *cs, *q0, *q1, *gfa, *grow, *Jq, *rc, *A5, *B5;
+  double *Kg, *kff, *Pst;        // gains, cost-to-go (upper triangle of P, then p)
   double *part;                   // [P_COUNT][N][Bp]
   double *ap, *ad, *gphi;         // [N][Bp]
   // per instance [Bp]
   double *mu, *rho, *phi0, *Dd, *fcur, *thcur, *logcur;
   double *res_stat, *res_eq, *res_ineq, *res_comp, *obj;
   int *status, *iters, *ls, *cur, *newstep;
+  int *redo, *force_gn, *gn_sticky, *curv_fail, *usedc, *stall;
   int *active_hist;               // [max_passes]
 };
 
@@ -97,6 +103,7 @@ __global__ __launch_bounds__(256) void k_init(Ws W, const double *__restrict__ x
   W.ls[b] = 0;
   W.cur[b] = 0;
   W.newstep[b] = 0;
+  W.redo[b] = 0; W.force_gn[b] = 0; W.gn_sticky[b] = 0; W.curv_fail[b] = 0; W.usedc[b] = 0; W.stall[b] = 0;
   W.mu[b] = mu0;
   W.rho[b] = 0.0;
   W.phi0[b] = 0.0;
@@ -161,8 +168,11 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
   const double mu = W.mu[b];
 
   // ---- step lengths of this trial --------------------------------------
+  // null pass: the current point is re-evaluated unchanged so that the step can be
+  // recomputed with the Gauss-Newton blocks (fallback of a failed curvature step)
+  const bool nostep = first || (W.redo[b] != 0);
   double alpha = 0.0, adual = 0.0;
-  if (!first) {
+  if (!nostep) {
     double a0 = 1.0, d0 = 1.0;
     for (int kk = 0; kk < N; kk++) {
       a0 = fmin(a0, W.ap[(size_t)kk * W.Bp + b]);
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
 #pragma unroll
   for (int j = 0; j < NV; j++) {
     double v = zc[IDX(j, k, b)];
-    if (!first) v += alpha * W.dz[IDX(j, k, b)];
+    if (!nostep) v += alpha * W.dz[IDX(j, k, b)];
     z[j] = v;
     zn[IDX(j, k, b)] = v;
   }
@@ -188,14 +198,14 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
     double v = 0.0;
     if (!first && k >= 1) {
       const double o = nc[IDX(j, k, b)];
-      v = o + alpha * (W.nunew[IDX(j, k, b)] - o);
+      v = nostep ? o : o + alpha * (W.nunew[IDX(j, k, b)] - o);
     }
     nuk[j] = v;
     nn[IDX(j, k, b)] = v;
     double w = 0.0;
     if (!first && k < N - 1) {
       const double o = nc[IDX(j, k + 1, b)];
-      w = o + alpha * (W.nunew[IDX(j, k + 1, b)] - o);
+      w = nostep ? o : o + alpha * (W.nunew[IDX(j, k + 1, b)] - o);
     }
     nun[j] = w;
   }
@@ -205,6 +215,11 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
   // ---- accumulators --------------------------------------------------------
   double gf[NV], q0[NV], q1[NV], rs[NV], Dg[NV], cs[NV];
   double Qqq[NQ][NQ];
+  double Cqq[C::CURV ? NQ : 1][C::CURV ? NQ : 1];  // sum_i (lambda_i + cN/h^2) grad^2 h_i of the distance rows
+#pragma unroll
+  for (int a = 0; a < (C::CURV ? NQ : 1); a++)
+#pragma unroll
+    for (int c = 0; c < (C::CURV ? NQ : 1); c++) Cqq[a][c] = 0;
 #pragma unroll
   for (int j = 0; j < NV; j++) { gf[j] = 0; q0[j] = 0; q1[j] = 0; rs[j] = 0; Dg[j] = 0; cs[j] = 0; }
 #pragma unroll
@@ -262,11 +277,14 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
 
   // one row with value g (slack already added), gradient: gq over q (FK rows) or a
   // single variable (var, sg); slack coupling when soft.
-  auto row_update = [&](int i, double g, bool is_fk, const double (&gq)[NQ], int var, double sg, bool soft) __attribute__((always_inline)) {
+  auto row_update = [&](int i, double g, bool is_fk, const double (&gq)[NQ], int var, double sg, bool soft) __attribute__((always_inline)) -> double {
     double tv, lv;
     if (first) {
       tv = g > kTMin ? g : kTMin;
       lv = mu / tv;
+    } else if (nostep) {
+      tv = tc[IDX(i, k, b)];
+      lv = lc[IDX(i, k, b)];
     } else {
       tv = tc[IDX(i, k, b)] + alpha * W.dtt[IDX(i, k, b)];
       lv = lc[IDX(i, k, b)] + adual * W.dlam[IDX(i, k, b)];
@@ -318,12 +336,13 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
         Dg[NX] += sig;
       }
     }
+    return lv;
   };
 
   // inverse-barrier objective on the first row of a module (constraint_avoidance.py:22-31)
-  auto avoid_update = [&](int mi, double h, bool is_fk, const double (&gq)[NQ], int var, double sg) __attribute__((always_inline)) {
+  auto avoid_update = [&](int mi, double h, bool is_fk, const double (&gq)[NQ], int var, double sg) __attribute__((always_inline)) -> double {
     const double wi = P(M.off_wconstr + mi);
-    if (wi == 0.0) return;
+    if (wi == 0.0) return 0.0;
     const double cN = (double)M.N * wi;
     if (!(h > 0.0)) bad = 1;
     f += cN / h;
@@ -349,6 +368,7 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
         }
       }
     }
+    return cN / (h * h);
   };
 
   for (int i = 0; i < M.nh; i++) {
@@ -363,6 +383,10 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
     int var = -1;
     double sg = 0.0;
     bool is_fk = true;
+    Vec3 Jc[NQ];  // Jacobian of the point (or point difference) the row measures
+    double cinv = 0.0;
+#pragma unroll
+    for (int a = 0; a < NQ; a++) Jc[a] = {0, 0, 0};
     if (kind == ROW_RADIAL) {
       // ||fk_l(q) - c_i|| - r_i - r_body (mpcBase.py:82-101)
       const Vec3 pl = kin.pos(M, ra);
@@ -373,8 +397,9 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
       const double dist = sqrt(dot(dv, dv));
       h = dist - P(o + 3) - rbody;
       const double inv = 1.0 / dist;
+      cinv = inv;
 #pragma unroll
-      for (int a = 0; a < NQ; a++) gq[a] = dot(dv, J[a]) * inv;
+      for (int a = 0; a < NQ; a++) { gq[a] = dot(dv, J[a]) * inv; Jc[a] = J[a]; }
     } else if (kind == ROW_LINEAR) {
       // |a.fk_l(q) + d| / ||a|| - r_body (LinearConstraints.py:25-40, utils.py:48-52)
       const Vec3 pl = kin.pos(M, ra);
@@ -398,8 +423,9 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
       const double dist = sqrt(dot(dv, dv));
       h = dist - 2.0 * rbody;
       const double inv = 1.0 / dist;
+      cinv = inv;
 #pragma unroll
-      for (int a = 0; a < NQ; a++) gq[a] = dot(dv, Ja[a] - Jb[a]) * inv;
+      for (int a = 0; a < NQ; a++) { Jc[a] = Ja[a] - Jb[a]; gq[a] = dot(dv, Jc[a]) * inv; }
     } else {
       // joint / velocity / input limits: sg * (z_var - limit)
       is_fk = false;
@@ -410,7 +436,8 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
       for (int j = 0; j < NV; j++) if (j == var) zv = z[j];
       h = sg * (zv - P(M.row_poff[i]));
     }
-    if (firstrow) avoid_update(mi, h, is_fk, gq, var, sg);
+    double cw = 0.0;
+    if (firstrow) cw = avoid_update(mi, h, is_fk, gq, var, sg);
     double g = h;
     if constexpr (NS > 0) g += sl;  // softened rows (intended InequalityManager.py:29-32)
     W.grow[IDX(i, k, b)] = g;
@@ -419,7 +446,18 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
 #pragma unroll
       for (int a = 0; a < NQ; a++) W.Jq[IDX(fi * NQ + a, k, b)] = gq[a];
     }
-    row_update(i, g, is_fk, gq, var, sg, NS > 0);
+    const double lvr = row_update(i, g, is_fk, gq, var, sg, NS > 0);
+    if constexpr (C::CURV) {
+      // exact Hessian of the distance rows when the kinematics are affine in q:
+      // grad^2 h = (J^T J - g g^T) / dist, weighted by the multiplier and the inverse-barrier term
+      if (M.use_curv && (kind == ROW_RADIAL || kind == ROW_SELF)) {
+        const double wgt = (lvr + cw) * cinv;
+#pragma unroll
+        for (int a = 0; a < NQ; a++)
+#pragma unroll
+          for (int c = a; c < NQ; c++) Cqq[a][c] += wgt * (dot(Jc[a], Jc[c]) - gq[a] * gq[c]);
+      }
+    }
   }
   // simple bounds (mpcModel.py:91-104): lower rows then upper rows, never softened
   {
@@ -488,7 +526,7 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
 #pragma unroll
     for (int j = 0; j < NX; j++) {
       double xk1 = zc[IDX(j, k + 1, b)];
-      if (!first) xk1 += alpha * W.dz[IDX(j, k + 1, b)];
+      if (!nostep) xk1 += alpha * W.dz[IDX(j, k + 1, b)];
       const double r = xn[j] - xk1;
       W.rc[IDX(j, k, b)] = r;
       req = fmax(req, fabs(r));
@@ -513,6 +551,15 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
     for (int a = 0; a < NQ; a++)
 #pragma unroll
       for (int c = a; c < NQ; c++) W.Qqq[IDX(s++, k, b)] = Qqq[a][c];
+  }
+  if constexpr (C::CURV) {
+    if (M.use_curv) {
+      int s = 0;
+#pragma unroll
+      for (int a = 0; a < NQ; a++)
+#pragma unroll
+        for (int c = a; c < NQ; c++) W.Cqq[IDX(s++, k, b)] = Cqq[a][c];
+    }
   }
 #pragma unroll
   for (int j = NQ; j < NV; j++) W.Dg[IDX(j - NQ, k, b)] = Dg[j];
@@ -609,9 +656,13 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
   double mu = W.mu[b];
   int status = ST_ACTIVE;
   int iters = W.iters[b];
+  const bool redo = (!first) && (W.redo[b] != 0);
 
   if (first) {
     if (badf != 0.0) status = -7;  // inverse-barrier row not strictly feasible at the start
+  } else if (redo) {
+    // null pass: same point, the step is recomputed below with the Gauss-Newton blocks
+    W.redo[b] = 0;
   } else {
     double gphi = 0.0, a0 = 1.0;
     for (int k = 0; k < N; k++) {
@@ -635,9 +686,22 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
     const double alpha = ldexp(a0, -ls);
     const double phi = f - mu * lgs + rho * th;
     const bool ok = (badf == 0.0) && (phi <= phi0 + kArmijo * alpha * Dd + 1e-13 * fabs(phi0));
+    const int usedc = W.usedc[b];
     if (!ok) {
       ls++;
-      if (ls > kLsMax) {
+      if (ls > (usedc ? kLsCurv - 1 : kLsMax)) {
+        if (usedc) {
+          // the curvature step failed its line search: recompute this iteration's step with
+          // the Gauss-Newton blocks (null pass next); latch after repeated failures
+          const int cf = W.curv_fail[b] + 1;
+          W.curv_fail[b] = cf;
+          if (cf >= kCurvFailMax) W.gn_sticky[b] = 1;
+          W.redo[b] = 1;
+          W.force_gn[b] = 1;
+          W.ls[b] = 0;
+          atomicAdd(&W.active_hist[pass], 1);
+          return;
+        }
         W.status[b] = -8;  // line search failure; the current iterate is returned
         return;
       }
@@ -645,54 +709,118 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
       atomicAdd(&W.active_hist[pass], 1);
       return;  // next sweep retries with alpha / 2
     }
+    if (usedc) W.curv_fail[b] = 0;
     iters++;
   }
   // ---- accept the trial point ------------------------------------------------------
   if (status == ST_ACTIVE) {
+    const double f_prev = W.fcur[b];
     W.cur[b] ^= 1;
     W.ls[b] = 0;
     W.fcur[b] = f;
     W.thcur[b] = th;
     W.logcur[b] = lgs;
-    W.iters[b] = iters;
-    W.res_stat[b] = rstat; W.res_eq[b] = req; W.res_ineq[b] = rineq; W.res_comp[b] = rcomp; W.obj[b] = f;
-    if (!first) {
-      // LOQO-style centrality rule with floors (DESIGN.md, section "Algorithm")
-      const double cnt = (double)N * (double)M.m;
-      const double avg = sumc / cnt;
-      const double xi = minc / avg;
-      double sg = 0.05 * (1.0 - xi) / xi;
-      if (sg > 2.0) sg = 2.0;
-      sg = 0.1 * sg * sg * sg;
-      if (sg < 0.02) sg = 0.02;
-      if (sg > 0.8) sg = 0.8;
-      mu = sg * avg;
-      if (mu < 0.1 * M.tol_comp) mu = 0.1 * M.tol_comp;
-      W.mu[b] = mu;
-      if (!(mu < kMuDiverged)) status = -7;
+    if (!redo) {
+      W.iters[b] = iters;
+      W.res_stat[b] = rstat; W.res_eq[b] = req; W.res_ineq[b] = rineq; W.res_comp[b] = rcomp; W.obj[b] = f;
+      if (!first) {
+        // LOQO-style centrality rule with floors (DESIGN.md, section "Algorithm")
+        const double cnt = (double)N * (double)M.m;
+        const double avg = sumc / cnt;
+        const double xi = minc / avg;
+        double sg = 0.05 * (1.0 - xi) / xi;
+        if (sg > 2.0) sg = 2.0;
+        sg = 0.1 * sg * sg * sg;
+        if (sg < 0.02) sg = 0.02;
+        if (sg > 0.8) sg = 0.8;
+        mu = sg * avg;
+        if (mu < 0.1 * M.tol_comp) mu = 0.1 * M.tol_comp;
+        W.mu[b] = mu;
+        if (!(mu < kMuDiverged)) status = -7;
+      }
+      if (status == ST_ACTIVE) {
+        if (!isfinite(rstat) || !isfinite(req) || !isfinite(rineq)) status = -6;
+        else if (rstat <= M.tol_stat && req <= M.tol_eq && rineq <= M.tol_ineq && rcomp <= M.tol_comp) status = 1;
+        else {
+          // acceptable termination: feasible, complementary, objective stagnant for acc_iters iterations
+          int stall = W.stall[b];
+          if (!first && req <= kAccFeas && rineq <= kAccFeas && rcomp <= kAccFeas &&
+              fabs(f - f_prev) <= M.acc_obj_tol * fmax(1.0, fabs(f)))
+            stall++;
+          else
+            stall = 0;
+          W.stall[b] = stall;
+          if (M.acc_iters > 0 && stall >= M.acc_iters) status = 2;
+          else if (iters >= M.max_iter) status = 0;
+        }
+      }
     }
-  }
-  if (status == ST_ACTIVE) {
-    if (!isfinite(rstat) || !isfinite(req) || !isfinite(rineq)) status = -6;
-    else if (rstat <= M.tol_stat && req <= M.tol_eq && rineq <= M.tol_ineq && rcomp <= M.tol_comp) status = 1;
-    else if (iters >= M.max_iter) status = 0;
   }
   if (status != ST_ACTIVE) {
     W.status[b] = status;
     return;
   }
+  // exact constraint curvature unless latched off or this is the fallback pass
+  bool usec = false;
+  if constexpr (C::CURV) usec = M.use_curv && !W.gn_sticky[b] && !W.force_gn[b] && (mu <= kCurvMu);
+  W.force_gn[b] = 0;
+  const double cwt = usec ? 1.0 : 0.0;  // Cqq is zero-filled when the model does not use it
 
-  // ---- Riccati backward recursion ------------------------------------------------------
+  // ---- Riccati recursion ---------------------------------------------------------------
+  // Explicit load phases: the inputs of stage k-1 are requested before stage k is computed
+  // (register double buffer), so one HBM/L2 round trip per stage is off the dependent chain.
+  // P and Qxx are kept as upper triangles.
+  constexpr bool DD = (C::ROBOT == RMPC_ROBOT_DIFFDRIVE);
+  constexpr int NQ2 = C::NQ2, NDG = NV - NQ, NP2 = NX * (NX + 1) / 2;
+  struct StageIn {
+    double qq[NQ2], dg[NDG], cs[NS > 0 ? NV : 1], q[NV], rc[NX];
+    double A5[DD ? 25 : 1], B5[DD ? 10 : 1];
+  };
+  auto load_stage = [&](int k, StageIn &s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NQ2; i++) {
+      double v = W.Qqq[IDX(i, k, b)];
+      if constexpr (C::CURV) v -= cwt * W.Cqq[IDX(i, k, b)];  // unconditional load, 0/1 weight
+      s.qq[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NDG; i++) s.dg[i] = W.Dg[IDX(i, k, b)];
+    if constexpr (NS > 0) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) s.cs[i] = W.cs[IDX(i, k, b)];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) s.q[i] = W.q0[IDX(i, k, b)] - mu * W.q1[IDX(i, k, b)];
+    // the last stage has no successor: these reads are in bounds, finite (zero-filled at create)
+    // and never used
+#pragma unroll
+    for (int i = 0; i < NX; i++) s.rc[i] = W.rc[IDX(i, k, b)];
+    if constexpr (DD) {
+#pragma unroll
+      for (int i = 0; i < 25; i++) s.A5[i] = W.A5[IDX(i, k, b)];
+#pragma unroll
+      for (int i = 0; i < 10; i++) s.B5[i] = W.B5[IDX(i, k, b)];
+    }
+  };
+  // upper-triangle accessors (indices are compile-time constants after unrolling)
+#define UP(Mx, i, j) ((i) <= (j) ? Mx[i][j] : Mx[j][i])
+
   double Pm[NX][NX], pv[NX];
+  bool chol_ok = true;
+  const double h = M.dt, h2 = 0.5 * M.dt * M.dt;
 #pragma unroll
   for (int i = 0; i < NX; i++) {
     pv[i] = 0;
 #pragma unroll
     for (int j = 0; j < NX; j++) Pm[i][j] = 0;
   }
-  bool chol_ok = true;
-  const double h = M.dt, h2 = 0.5 * M.dt * M.dt;
+  constexpr bool PREFETCH = (NX <= 8);  // the 14-state arm has no registers to spare for a second buffer
+  StageIn cur, nxt;
+  if constexpr (PREFETCH) load_stage(N - 1, cur);
   for (int k = N - 1; k >= 0; k--) {
+    if constexpr (PREFETCH) load_stage(k > 0 ? k - 1 : 0, nxt);
+    else load_stage(k, cur);
+    asm volatile("" ::: "memory");  // keep the loads above the computation of stage k
     double Qxx[NX][NX], Qxw[NX][NW], Qww[NW][NW], qx[NX], qw[NW];
 #pragma unroll
     for (int i = 0; i < NX; i++) {
@@ -710,60 +838,51 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
 #pragma unroll
       for (int a = 0; a < NQ; a++)
 #pragma unroll
-        for (int c = a; c < NQ; c++) {
-          const double v = W.Qqq[IDX(s++, k, b)];
-          Qxx[a][c] = v;
-          Qxx[c][a] = v;
-        }
+        for (int c = a; c < NQ; c++) Qxx[a][c] = cur.qq[s++];
     }
 #pragma unroll
-    for (int j = NQ; j < NX; j++) Qxx[j][j] = W.Dg[IDX(j - NQ, k, b)];
+    for (int j = NQ; j < NX; j++) Qxx[j][j] = cur.dg[j - NQ];
 #pragma unroll
-    for (int j = 0; j < NW; j++) Qww[j][j] = W.Dg[IDX(NX + j - NQ, k, b)];
+    for (int j = 0; j < NW; j++) Qww[j][j] = cur.dg[NX + j - NQ];
     if constexpr (NS > 0) {
 #pragma unroll
-      for (int j = 0; j < NX; j++) Qxw[j][0] = W.cs[IDX(j, k, b)];
+      for (int j = 0; j < NX; j++) Qxw[j][0] = cur.cs[j];
 #pragma unroll
-      for (int j = 0; j < NU; j++) {
-        const double v = W.cs[IDX(NX + 1 + j, k, b)];
-        Qww[0][1 + j] = v;
-        Qww[1 + j][0] = v;
-      }
+      for (int j = 0; j < NU; j++) Qww[0][1 + j] = cur.cs[NX + 1 + j];
     }
 #pragma unroll
-    for (int j = 0; j < NX; j++) qx[j] = W.q0[IDX(j, k, b)] - mu * W.q1[IDX(j, k, b)];
+    for (int j = 0; j < NX; j++) qx[j] = cur.q[j];
 #pragma unroll
-    for (int j = 0; j < NW; j++) qw[j] = W.q0[IDX(NX + j, k, b)] - mu * W.q1[IDX(NX + j, k, b)];
+    for (int j = 0; j < NW; j++) qw[j] = cur.q[NX + j];
 
     if (k < N - 1) {
-      double rc[NX], Pc[NX];
-#pragma unroll
-      for (int j = 0; j < NX; j++) rc[j] = W.rc[IDX(j, k, b)];
+      double Pc[NX];
 #pragma unroll
       for (int i = 0; i < NX; i++) {
         double s = pv[i];
 #pragma unroll
-        for (int l = 0; l < NX; l++) s += Pm[i][l] * rc[l];
+        for (int l = 0; l < NX; l++) s += UP(Pm, i, l) * cur.rc[l];
         Pc[i] = s;
       }
-      if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
-        // A = [I hI; 0 I], B = [h2 I; h I] (u columns).  Blocks of P: 11, 12, 21, 22.
+      if constexpr (!DD) {
+        // A = [I hI; 0 I], B = [h2 I; h I] (u columns): O(n^2) block algebra
 #pragma unroll
         for (int i = 0; i < NQ; i++) {
 #pragma unroll
           for (int j = 0; j < NQ; j++) {
-            const double p11 = Pm[i][j], p12 = Pm[i][NQ + j], p21 = Pm[NQ + i][j], p22 = Pm[NQ + i][NQ + j];
-            const double pa12 = h * p11 + p12;           // (PA)_12
-            const double pa22 = h * p21 + p22;           // (PA)_22
-            const double pb1 = h2 * p11 + h * p12;       // (PB)_1
-            const double pb2 = h2 * p21 + h * p22;       // (PB)_2
-            Qxx[i][j] += p11;
+            const double p11 = UP(Pm, i, j), p12 = UP(Pm, i, NQ + j), p21 = UP(Pm, NQ + i, j), p22 = UP(Pm, NQ + i, NQ + j);
+            const double pa12 = h * p11 + p12;
+            const double pa22 = h * p21 + p22;
+            const double pb1 = h2 * p11 + h * p12;
+            const double pb2 = h2 * p21 + h * p22;
+            if (i <= j) {
+              Qxx[i][j] += p11;
+              Qxx[NQ + i][NQ + j] += h * pa12 + pa22;
+              Qww[NS + i][NS + j] += h2 * pb1 + h * pb2;
+            }
             Qxx[i][NQ + j] += pa12;
-            Qxx[NQ + i][j] += h * p11 + p21;
-            Qxx[NQ + i][NQ + j] += h * pa12 + pa22;
             Qxw[i][NS + j] += pb1;
             Qxw[NQ + i][NS + j] += h * pb1 + pb2;
-            Qww[NS + i][NS + j] += h2 * pb1 + h * pb2;
           }
           qx[i] += Pc[i];
           qx[NQ + i] += h * Pc[i] + Pc[NQ + i];
@@ -783,9 +902,9 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
 #pragma unroll
         for (int r = 0; r < 5; r++) {
 #pragma unroll
-          for (int c = 0; c < 5; c++) A[map[r]][map[c]] = W.A5[IDX(r * 5 + c, k, b)];
+          for (int c = 0; c < 5; c++) A[map[r]][map[c]] = cur.A5[r * 5 + c];
 #pragma unroll
-          for (int c = 0; c < 2; c++) Bm[map[r]][c] = W.B5[IDX(r * 2 + c, k, b)];
+          for (int c = 0; c < 2; c++) Bm[map[r]][c] = cur.B5[r * 2 + c];
         }
         double PA[NX][NX], PB[NX][NU];
 #pragma unroll
@@ -794,21 +913,21 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
           for (int j = 0; j < NX; j++) {
             double s = 0;
 #pragma unroll
-            for (int l = 0; l < NX; l++) s += Pm[i][l] * A[l][j];
+            for (int l = 0; l < NX; l++) s += UP(Pm, i, l) * A[l][j];
             PA[i][j] = s;
           }
 #pragma unroll
           for (int j = 0; j < NU; j++) {
             double s = 0;
 #pragma unroll
-            for (int l = 0; l < NX; l++) s += Pm[i][l] * Bm[l][j];
+            for (int l = 0; l < NX; l++) s += UP(Pm, i, l) * Bm[l][j];
             PB[i][j] = s;
           }
         }
 #pragma unroll
         for (int i = 0; i < NX; i++) {
 #pragma unroll
-          for (int j = 0; j < NX; j++) {
+          for (int j = i; j < NX; j++) {
             double s = 0;
 #pragma unroll
             for (int l = 0; l < NX; l++) s += A[l][i] * PA[l][j];
@@ -829,7 +948,7 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
 #pragma unroll
         for (int i = 0; i < NU; i++) {
 #pragma unroll
-          for (int j = 0; j < NU; j++) {
+          for (int j = i; j < NU; j++) {
             double s = 0;
 #pragma unroll
             for (int l = 0; l < NX; l++) s += Bm[l][i] * PB[l][j];
@@ -842,32 +961,43 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
         }
       }
     }
-    // gains
-    if (!chol_inplace<NW>(Qww)) chol_ok = false;
+    // Cholesky of Qww (upper triangle in, lower factor out)
+    double L[NW][NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      double dg = Qww[j][j];
+#pragma unroll
+      for (int l = 0; l < j; l++) dg -= L[j][l] * L[j][l];
+      if (!(dg > 0.0)) chol_ok = false;
+      dg = sqrt(dg);
+      L[j][j] = dg;
+      const double inv = 1.0 / dg;
+#pragma unroll
+      for (int i = j + 1; i < NW; i++) {
+        double s = Qww[j][i];
+#pragma unroll
+        for (int l = 0; l < j; l++) s -= L[i][l] * L[j][l];
+        L[i][j] = s * inv;
+      }
+    }
     double Kx[NW][NX], kf[NW];
 #pragma unroll
     for (int j = 0; j < NX; j++) {
       double col[NW];
 #pragma unroll
       for (int i = 0; i < NW; i++) col[i] = -Qxw[j][i];
-      chol_solve<NW>(Qww, col);
+      chol_solve<NW>(L, col);
 #pragma unroll
       for (int i = 0; i < NW; i++) Kx[i][j] = col[i];
     }
 #pragma unroll
     for (int i = 0; i < NW; i++) kf[i] = -qw[i];
-    chol_solve<NW>(Qww, kf);
-#pragma unroll
-    for (int i = 0; i < NW; i++) {
-      W.kff[IDX(i, k, b)] = kf[i];
-#pragma unroll
-      for (int j = 0; j < NX; j++) W.Kg[IDX(i * NX + j, k, b)] = Kx[i][j];
-    }
-    // cost-to-go
+    chol_solve<NW>(L, kf);
+    // cost-to-go (upper triangle)
 #pragma unroll
     for (int i = 0; i < NX; i++) {
 #pragma unroll
-      for (int j = 0; j < NX; j++) {
+      for (int j = i; j < NX; j++) {
         double s = Qxx[i][j];
 #pragma unroll
         for (int l = 0; l < NW; l++) s += Qxw[i][l] * Kx[l][j];
@@ -879,119 +1009,125 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
       pv[i] = s;
     }
 #pragma unroll
-    for (int i = 0; i < NX; i++)
+    for (int i = 0; i < NW; i++) {
+      W.kff[IDX(i, k, b)] = kf[i];
 #pragma unroll
-      for (int j = i + 1; j < NX; j++) {
-        const double a = 0.5 * (Pm[i][j] + Pm[j][i]);
-        Pm[i][j] = a;
-        Pm[j][i] = a;
-      }
+      for (int j = 0; j < NX; j++) W.Kg[IDX(i * NX + j, k, b)] = Kx[i][j];
+    }
+    {
+      int s = 0;
+#pragma unroll
+      for (int i = 0; i < NX; i++)
+#pragma unroll
+        for (int j = i; j < NX; j++) W.Pst[IDX(s++, k, b)] = Pm[i][j];
+#pragma unroll
+      for (int i = 0; i < NX; i++) W.Pst[IDX(NP2 + i, k, b)] = pv[i];
+    }
+    if constexpr (PREFETCH) cur = nxt;
   }
   if (!chol_ok) {
+    if (usec) {
+      // reduced Hessian not positive definite with the curvature terms: recompute this
+      // iteration's step with the Gauss-Newton blocks (null pass next); not counted as a
+      // line-search failure
+      W.redo[b] = 1;
+      W.force_gn[b] = 1;
+      W.usedc[b] = 0;
+      atomicAdd(&W.active_hist[pass], 1);
+      return;
+    }
     W.status[b] = -5;
     return;
   }
+  W.usedc[b] = usec ? 1 : 0;
 
-  // ---- forward rollout ---------------------------------------------------------------------
+  // ---- forward rollout + costates nu+_k = P_k dx_k + p_k ------------------------------------
+  struct FwdIn {
+    double Kx[NW * NX], kf[NW], Pu[NP2], pp[NX], rc[NX];
+    double A5[DD ? 25 : 1], B5[DD ? 10 : 1];
+  };
+  auto load_fwd = [&](int k, FwdIn &s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NW * NX; i++) s.Kx[i] = W.Kg[IDX(i, k, b)];
+#pragma unroll
+    for (int i = 0; i < NW; i++) s.kf[i] = W.kff[IDX(i, k, b)];
+#pragma unroll
+    for (int i = 0; i < NP2; i++) s.Pu[i] = W.Pst[IDX(i, k, b)];
+#pragma unroll
+    for (int i = 0; i < NX; i++) s.pp[i] = W.Pst[IDX(NP2 + i, k, b)];
+#pragma unroll
+    for (int i = 0; i < NX; i++) s.rc[i] = W.rc[IDX(i, k, b)];
+    if constexpr (DD) {
+#pragma unroll
+      for (int i = 0; i < 25; i++) s.A5[i] = W.A5[IDX(i, k, b)];
+#pragma unroll
+      for (int i = 0; i < 10; i++) s.B5[i] = W.B5[IDX(i, k, b)];
+    }
+  };
   double dx[NX];
 #pragma unroll
   for (int j = 0; j < NX; j++) dx[j] = 0.0;
+  FwdIn fc, fn;
+  if constexpr (PREFETCH) load_fwd(0, fc);
   for (int k = 0; k < N; k++) {
+    if constexpr (PREFETCH) load_fwd(k < N - 1 ? k + 1 : k, fn);
+    else load_fwd(k, fc);
+    asm volatile("" ::: "memory");
     double dw[NW];
 #pragma unroll
     for (int i = 0; i < NW; i++) {
-      double s = W.kff[IDX(i, k, b)];
+      double s = fc.kf[i];
 #pragma unroll
-      for (int j = 0; j < NX; j++) s += W.Kg[IDX(i * NX + j, k, b)] * dx[j];
+      for (int j = 0; j < NX; j++) s += fc.Kx[i * NX + j] * dx[j];
       dw[i] = s;
     }
 #pragma unroll
     for (int j = 0; j < NX; j++) W.dz[IDX(j, k, b)] = dx[j];
 #pragma unroll
     for (int i = 0; i < NW; i++) W.dz[IDX(NX + i, k, b)] = dw[i];
+    if (k >= 1) {
+      // upper-triangle P_k: element (i, j), i <= j, at i*NX - i(i-1)/2 + (j - i)
+#pragma unroll
+      for (int i = 0; i < NX; i++) {
+        double s = fc.pp[i];
+#pragma unroll
+        for (int j = 0; j < NX; j++) {
+          const int lo = i < j ? i : j, hi = i < j ? j : i;
+          s += fc.Pu[lo * NX - lo * (lo - 1) / 2 + (hi - lo)] * dx[j];
+        }
+        W.nunew[IDX(i, k, b)] = s;
+      }
+    }
     if (k < N - 1) {
       double dxn[NX];
-      if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
+      if constexpr (!DD) {
 #pragma unroll
         for (int i = 0; i < NQ; i++) {
-          dxn[i] = W.rc[IDX(i, k, b)] + dx[i] + h * dx[NQ + i] + h2 * dw[NS + i];
-          dxn[NQ + i] = W.rc[IDX(NQ + i, k, b)] + dx[NQ + i] + h * dw[NS + i];
+          dxn[i] = fc.rc[i] + dx[i] + h * dx[NQ + i] + h2 * dw[NS + i];
+          dxn[NQ + i] = fc.rc[NQ + i] + dx[NQ + i] + h * dw[NS + i];
         }
       } else {
         constexpr int map[5] = {0, 1, 2, 6, 7};
 #pragma unroll
-        for (int j = 0; j < NX; j++) dxn[j] = W.rc[IDX(j, k, b)];
+        for (int j = 0; j < NX; j++) dxn[j] = fc.rc[j];
 #pragma unroll
         for (int j = 3; j < 6; j++) dxn[j] += dx[j];
 #pragma unroll
         for (int r = 0; r < 5; r++) {
           double s = 0;
 #pragma unroll
-          for (int c = 0; c < 5; c++) s += W.A5[IDX(r * 5 + c, k, b)] * dx[map[c]];
+          for (int c = 0; c < 5; c++) s += fc.A5[r * 5 + c] * dx[map[c]];
 #pragma unroll
-          for (int c = 0; c < 2; c++) s += W.B5[IDX(r * 2 + c, k, b)] * dw[NS + c];
+          for (int c = 0; c < 2; c++) s += fc.B5[r * 2 + c] * dw[NS + c];
           dxn[map[r]] += s;
         }
       }
 #pragma unroll
       for (int j = 0; j < NX; j++) dx[j] = dxn[j];
     }
+    if constexpr (PREFETCH) fc = fn;
   }
-
-  // ---- costates nu+_k = (Q dz)_x + q_x + A^T nu+_{k+1}, backward ------------------------------
-  double nu1[NX];
-#pragma unroll
-  for (int j = 0; j < NX; j++) nu1[j] = 0.0;
-  for (int k = N - 1; k >= 1; k--) {
-    double dzk[NV];
-#pragma unroll
-    for (int j = 0; j < NV; j++) dzk[j] = W.dz[IDX(j, k, b)];
-    double r[NX];
-#pragma unroll
-    for (int j = 0; j < NX; j++) r[j] = W.q0[IDX(j, k, b)] - mu * W.q1[IDX(j, k, b)];
-    {
-      int s = 0;
-#pragma unroll
-      for (int a = 0; a < NQ; a++)
-#pragma unroll
-        for (int c = a; c < NQ; c++) {
-          const double v = W.Qqq[IDX(s++, k, b)];
-          r[a] += v * dzk[c];
-          if (c != a) r[c] += v * dzk[a];
-        }
-    }
-#pragma unroll
-    for (int j = NQ; j < NX; j++) r[j] += W.Dg[IDX(j - NQ, k, b)] * dzk[j];
-    if constexpr (NS > 0) {
-#pragma unroll
-      for (int j = 0; j < NX; j++) r[j] += W.cs[IDX(j, k, b)] * dzk[NX];
-    }
-    if (k < N - 1) {
-      if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
-#pragma unroll
-        for (int i = 0; i < NQ; i++) {
-          r[i] += nu1[i];
-          r[NQ + i] += h * nu1[i] + nu1[NQ + i];
-        }
-      } else {
-        constexpr int map[5] = {0, 1, 2, 6, 7};
-#pragma unroll
-        for (int j = 3; j < 6; j++) r[j] += nu1[j];
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-          double s = 0;
-#pragma unroll
-          for (int rr = 0; rr < 5; rr++) s += W.A5[IDX(rr * 5 + c, k, b)] * nu1[map[rr]];
-          r[map[c]] += s;
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NX; j++) {
-      nu1[j] = r[j];
-      W.nunew[IDX(j, k, b)] = r[j];
-    }
-  }
+#undef UP
   W.newstep[b] = 1;
   atomicAdd(&W.active_hist[pass], 1);
 }
@@ -1249,6 +1385,24 @@ static int build_model(const rmpc_desc &d, DevModel &M, std::string &err) {
   M.tol_ineq = d.tol_ineq > 0 ? d.tol_ineq : 1e-8;
   M.tol_comp = d.tol_comp > 0 ? d.tol_comp : 1e-6;
   M.mu0 = d.mu0 > 0 ? d.mu0 : 1.0;
+  M.acc_iters = d.acc_iters < 0 ? 0 : d.acc_iters;
+  M.acc_obj_tol = d.acc_obj_tol > 0 ? d.acc_obj_tol : 1e-8;
+  // exact curvature of the distance rows: holonomic chain, no slack, n <= 3 and every frame a
+  // distance row refers to moves affinely with q (prismatic joints, or revolute at the frame itself)
+  auto affine = [&](int f) {
+    for (int j = 0; j <= f; j++)
+      if (d.joint_type[j] == RMPC_JOINT_REVOLUTE && j != f) return false;
+    return true;
+  };
+  bool curv = d.robot == RMPC_ROBOT_CHAIN && d.ns == 0 && d.n <= 3;
+  for (int mi = 0; mi < d.n_modules && curv; mi++) {
+    if (d.module_kind[mi] == RMPC_MOD_RADIAL)
+      for (int l = 0; l < d.n_links; l++) curv = curv && affine(d.link_frame[l]);
+    if (d.module_kind[mi] == RMPC_MOD_SELFCOLLISION)
+      for (int p = 0; p < d.n_pairs; p++) curv = curv && affine(d.pair_frame[p][0]) && affine(d.pair_frame[p][1]);
+  }
+  M.use_curv = curv ? 1 : 0;
+  if (getenv("RMPC_NO_CURV")) M.use_curv = 0;  // debugging aid
   return 0;
 }
 
@@ -1283,6 +1437,7 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   W.dlam = c.take<double>(S * M.m);
   W.nunew = c.take<double>(S * M.nx);
   W.Qqq = c.take<double>(S * nq2);
+  W.Cqq = c.take<double>(S * nq2);
   W.Dg = c.take<double>(S * (M.nv - nq));
   W.cs = c.take<double>(S * M.nv);
   W.q0 = c.take<double>(S * M.nv);
@@ -1295,6 +1450,7 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   W.B5 = c.take<double>(S * 10);
   W.Kg = c.take<double>(S * M.nw * M.nx);
   W.kff = c.take<double>(S * M.nw);
+  W.Pst = c.take<double>(S * (M.nx * (M.nx + 1) / 2 + M.nx));
   W.part = c.take<double>(S * P_COUNT);
   W.ap = c.take<double>(S);
   W.ad = c.take<double>(S);
@@ -1302,7 +1458,7 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   double **per[] = {&W.mu, &W.rho, &W.phi0, &W.Dd, &W.fcur, &W.thcur, &W.logcur,
                     &W.res_stat, &W.res_eq, &W.res_ineq, &W.res_comp, &W.obj};
   for (auto pp : per) *pp = c.take<double>(Bp);
-  int **peri[] = {&W.status, &W.iters, &W.ls, &W.cur, &W.newstep};
+  int **peri[] = {&W.status, &W.iters, &W.ls, &W.cur, &W.newstep, &W.redo, &W.force_gn, &W.gn_sticky, &W.curv_fail, &W.usedc, &W.stall};
   for (auto pp : peri) *pp = c.take<int>(Bp);
   W.active_hist = c.take<int>(max_passes + 8);
   return (c.off + 255) & ~(size_t)255;
@@ -1318,11 +1474,13 @@ static void fill_lane_bytes(rmpc_handle *h, int B) {
   const int nq2 = M.n * (M.n + 1) / 2;
   const int64_t dd = (M.robot == RMPC_ROBOT_DIFFDRIVE) ? 35 : 0;
   const int64_t sweep_rd = M.nv * 2 + M.m * 4 + M.nx * 4 + M.npar + M.nx * 2 + 2 * M.N;
-  const int64_t sweep_wr = M.nv + 2 * M.m + M.nx + nq2 + (M.nv - M.n) + (M.ns ? M.nv : 0) + 3 * M.nv + M.nh +
-                           M.nfk * M.n + M.nx + dd + P_COUNT;
-  const int64_t ric_rd = P_COUNT + 3 + 2 * (nq2 + (M.nv - M.n) + (M.ns ? M.nv : 0) + 2 * M.nv) + 2 * M.nx + 2 * dd +
-                         (M.nw * M.nx + M.nw) + M.nv;
-  const int64_t ric_wr = (M.nw * M.nx + M.nw) + M.nv + M.nx;
+  const int64_t sweep_wr = M.nv + 2 * M.m + M.nx + nq2 + (M.use_curv ? nq2 : 0) + (M.nv - M.n) + (M.ns ? M.nv : 0) +
+                           3 * M.nv + M.nh + M.nfk * M.n + M.nx + dd + P_COUNT;
+  const int64_t np2 = M.nx * (M.nx + 1) / 2 + M.nx;
+  const int64_t curv = M.use_curv ? nq2 : 0;
+  const int64_t ric_rd = P_COUNT + 3 + (nq2 + curv + (M.nv - M.n) + (M.ns ? M.nv : 0) + 2 * M.nv) + 2 * M.nx + 2 * dd +
+                         (M.nw * M.nx + M.nw) + np2;
+  const int64_t ric_wr = (M.nw * M.nx + M.nw) + np2 + M.nv + M.nx;
   const int64_t step_rd = 3 * M.nv + 2 * M.m + M.nh + M.nfk * M.n;
   const int64_t step_wr = 2 * M.m + 3;
   h->lane_bytes[K_PACK] = 16 * ((int64_t)B * (M.nx + (int64_t)M.N * (M.nv + M.npar)));

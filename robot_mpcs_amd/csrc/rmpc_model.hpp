@@ -52,6 +52,9 @@ struct DevModel {
   double lb_val[RMPC_NV_MAX], ub_val[RMPC_NV_MAX];
   int max_iter;
   double tol_stat, tol_eq, tol_ineq, tol_comp, mu0;
+  int use_curv;      // exact curvature of the distance rows (affine kinematics, no slack, n <= 3)
+  int acc_iters;     // acceptable termination window (0 = off)
+  double acc_obj_tol;
 };
 
 struct Vec3 {
@@ -75,6 +78,7 @@ struct Cfg {
   static constexpr int NW = NS_ + NU;
   static constexpr int NQ2 = NQ_ * (NQ_ + 1) / 2;
   static constexpr int NR = 5;  // reduced diff-drive state (x, y, theta, v, omega)
+  static constexpr bool CURV = (ROBOT_ == RMPC_ROBOT_CHAIN) && (NS_ == 0) && (NQ_ <= 3);
 };
 
 // ---------------------------------------------------------------------------

@@ -50,6 +50,8 @@ DEFAULT_OPTIONS = {
     "tol_ineq": 1e-8,
     "tol_comp": 1e-6,
     "mu0": 1.0,
+    "acc_iters": 8,       # acceptable termination window (0 disables)
+    "acc_obj_tol": 1e-8,  # relative objective change counted as stagnation
 }
 
 

@@ -26,7 +26,7 @@ def main():
         sc = make_scenario(name, B=B, seed=seed)
         o = Oracle(sc.desc)
         r = o.solve_batch(sc.xinit, sc.x0, sc.params)
-        assert np.all(r["exitflag"] == 1), (name, r["exitflag"])
+        assert np.all(np.isin(r["exitflag"], (1, 2))), (name, r["exitflag"])
         # stage-level vectors of the first instance at its start point
         p0 = sc.params[0].reshape(o.N, o.npar)[0]
         e = o.eval_stage(sc.x0[0, 0], p0)
