@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rmpc_model.hpp"
@@ -59,7 +60,8 @@ struct Ws {
   double *Qqq, *Cqq, *Dg, *cs, *q0, *q1, *gfa, *grow, *Jq, *rc, *A5, *B5;
   double *Kg, *kff, *Pst;        // gains, cost-to-go (upper triangle of P, then p)
   double *part;                   // [P_COUNT][N][Bp]
-  double *ap, *ad, *gphi;         // [N][Bp]
+  double *gphi;                   // [N][Bp]
+  unsigned long long *amin_p, *amin_d;  // [Bp] fraction-to-the-boundary step lengths (bits of a positive double)
   // per instance [Bp]
   double *mu, *rho, *phi0, *Dd, *fcur, *thcur, *logcur;
   double *res_stat, *res_eq, *res_ineq, *res_comp, *obj;
@@ -103,6 +105,8 @@ __global__ __launch_bounds__(256) void k_init(Ws W, const double *__restrict__ x
   W.ls[b] = 0;
   W.cur[b] = 0;
   W.newstep[b] = 0;
+  W.amin_p[b] = (unsigned long long)__double_as_longlong(1.0);
+  W.amin_d[b] = (unsigned long long)__double_as_longlong(1.0);
   W.redo[b] = 0; W.force_gn[b] = 0; W.gn_sticky[b] = 0; W.curv_fail[b] = 0; W.usedc[b] = 0; W.stall[b] = 0;
   W.mu[b] = mu0;
   W.rho[b] = 0.0;
@@ -153,9 +157,18 @@ __global__ __launch_bounds__(256) void k_unpack(Ws W, double *__restrict__ zout,
 // ===========================================================================
 // k_sweep: stage-parallel function / Jacobian evaluation + condensing
 // ===========================================================================
+// Rows are processed in two groups so that every register array is indexed by an
+// unrolled loop counter only and loads can be issued in batches:
+//   * FK rows (distance / plane rows), grouped by kinematic slot (static slot loop,
+//     short runtime loop over the rows of the slot);
+//   * single-variable rows (limits and simple bounds), grouped by variable (static
+//     loops; absent entries load row 0 and are masked -- a branch around a load,
+//     even a wave-uniform one, makes hipcc wait for every element separately).
 template <class C>
-__global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, const int B, const int first) {
+__global__ __launch_bounds__(256) void k_sweep(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
+                                               const int B, const int first) {
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV;
+  const DevTables &T = *Tp;
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int b = gid % W.Bp;
   const int k = gid / W.Bp;  // uniform per wavefront (Bp % 64 == 0)
@@ -163,8 +176,19 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
   if (W.status[b] != ST_ACTIVE) return;
   const int N = M.N;
   const int cur = W.cur[b], nxt = cur ^ 1;
-  const double *zc = W.z[cur], *tc = W.t[cur], *lc = W.lam[cur], *nc = W.nu[cur];
-  double *zn = W.z[nxt], *tn = W.t[nxt], *ln = W.lam[nxt], *nn = W.nu[nxt];
+  const double *__restrict__ zc = W.z[cur];
+  const double *__restrict__ tc = W.t[cur];
+  const double *__restrict__ lc = W.lam[cur];
+  const double *__restrict__ nc = W.nu[cur];
+  double *__restrict__ zn = W.z[nxt];
+  double *__restrict__ tn = W.t[nxt];
+  double *__restrict__ ln = W.lam[nxt];
+  double *__restrict__ nn = W.nu[nxt];
+  const double *__restrict__ pp = W.p;
+  const double *__restrict__ dzp = W.dz;
+  const double *__restrict__ dtp = W.dtt;
+  const double *__restrict__ dlp = W.dlam;
+  const double *__restrict__ nup = W.nunew;
   const double mu = W.mu[b];
 
   // ---- step lengths of this trial --------------------------------------
@@ -173,44 +197,43 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
   const bool nostep = first || (W.redo[b] != 0);
   double alpha = 0.0, adual = 0.0;
   if (!nostep) {
-    double a0 = 1.0, d0 = 1.0;
-    for (int kk = 0; kk < N; kk++) {
-      a0 = fmin(a0, W.ap[(size_t)kk * W.Bp + b]);
-      d0 = fmin(d0, W.ad[(size_t)kk * W.Bp + b]);
-    }
-    alpha = ldexp(a0, -W.ls[b]);
-    adual = d0;
+    alpha = ldexp(__longlong_as_double((long long)W.amin_p[b]), -W.ls[b]);
+    adual = __longlong_as_double((long long)W.amin_d[b]);
   }
+  const double am = nostep ? 0.0 : alpha;   // multiplies the steps (0 on first / null passes:
+  const double dm = nostep ? 0.0 : adual;   //  the step arrays are zero-filled or stale but finite)
 
-  // ---- trial stage vector ------------------------------------------------
-  double z[NV];
+  // ---- trial stage vector, costates, next stage's state ------------------------
+  double z[NV], xk1[NX], nuk[NX], nun[NX];
+  {
+    double zo[NV], dzo[NV];
 #pragma unroll
-  for (int j = 0; j < NV; j++) {
-    double v = zc[IDX(j, k, b)];
-    if (!nostep) v += alpha * W.dz[IDX(j, k, b)];
-    z[j] = v;
-    zn[IDX(j, k, b)] = v;
-  }
-  // multipliers of the dynamics: nu_k (k >= 1), nu_{k+1} (k < N-1)
-  double nuk[NX], nun[NX];
+    for (int j = 0; j < NV; j++) { zo[j] = zc[IDX(j, k, b)]; dzo[j] = dzp[IDX(j, k, b)]; }
+    const int k1 = k < N - 1 ? k + 1 : k;  // clamped: loads stay unconditional
+    double x1[NX], dx1[NX], n0[NX], n0n[NX], n1[NX], n1n[NX];
 #pragma unroll
-  for (int j = 0; j < NX; j++) {
-    double v = 0.0;
-    if (!first && k >= 1) {
-      const double o = nc[IDX(j, k, b)];
-      v = nostep ? o : o + alpha * (W.nunew[IDX(j, k, b)] - o);
+    for (int j = 0; j < NX; j++) {
+      x1[j] = zc[IDX(j, k1, b)]; dx1[j] = dzp[IDX(j, k1, b)];
+      n0[j] = nc[IDX(j, k, b)];  n0n[j] = nup[IDX(j, k, b)];
+      n1[j] = nc[IDX(j, k1, b)]; n1n[j] = nup[IDX(j, k1, b)];
     }
-    nuk[j] = v;
-    nn[IDX(j, k, b)] = v;
-    double w = 0.0;
-    if (!first && k < N - 1) {
-      const double o = nc[IDX(j, k + 1, b)];
-      w = nostep ? o : o + alpha * (W.nunew[IDX(j, k + 1, b)] - o);
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      z[j] = nostep ? zo[j] : zo[j] + alpha * dzo[j];
+      zn[IDX(j, k, b)] = z[j];
     }
-    nun[j] = w;
+#pragma unroll
+    for (int j = 0; j < NX; j++) {
+      xk1[j] = nostep ? x1[j] : x1[j] + alpha * dx1[j];
+      double v = 0.0, w = 0.0;
+      if (!first && k >= 1) v = nostep ? n0[j] : n0[j] + alpha * (n0n[j] - n0[j]);
+      if (!first && k < N - 1) w = nostep ? n1[j] : n1[j] + alpha * (n1n[j] - n1[j]);
+      nuk[j] = v;
+      nun[j] = w;
+      nn[IDX(j, k, b)] = v;
+    }
   }
-
-  auto P = [&](int off) __attribute__((always_inline)) -> double { return W.p[IDX(off, k, b)]; };
+  auto P = [&](int off) __attribute__((always_inline)) -> double { return pp[IDX(off, k, b)]; };
 
   // ---- accumulators --------------------------------------------------------
   double gf[NV], q0[NV], q1[NV], rs[NV], Dg[NV], cs[NV];
@@ -228,32 +251,8 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
     for (int c = 0; c < NQ; c++) Qqq[a][c] = 0;
   double f = 0.0;
   int bad = 0;
+  double theta = 0.0, logsum = 0.0, rineq = 0.0, rcomp = 0.0, sumc = 0.0, minc = 1e300;
 
-  // ---- kinematics ------------------------------------------------------------
-  Kin<C> kin;
-  {
-    double q[NQ];
-#pragma unroll
-    for (int j = 0; j < NQ; j++) q[j] = z[j];
-    kin.compute(M, q);
-  }
-
-  // ---- GoalReaching (goal_reaching.py:19-33), Gauss-Newton Hessian -----------
-  if (M.has_goal) {
-    const Vec3 pe = kin.pos(M, M.end_frame);
-    Vec3 J[NQ];
-    kin.jac(M, M.end_frame, pe, J);
-    const double e0 = pe.x - P(M.off_goal), e1 = pe.y - P(M.off_goal + 1), e2 = pe.z - P(M.off_goal + 2);
-    const double w0 = P(M.off_wgoal), w1 = P(M.off_wgoal + 1), w2 = P(M.off_wgoal + 2);
-    f += w0 * e0 * e0 + w1 * e1 * e1 + w2 * e2 * e2;
-#pragma unroll
-    for (int a = 0; a < NQ; a++) {
-      gf[a] += 2.0 * (w0 * e0 * J[a].x + w1 * e1 * J[a].y + w2 * e2 * J[a].z);
-#pragma unroll
-      for (int c = a; c < NQ; c++)
-        Qqq[a][c] += 2.0 * (w0 * J[a].x * J[c].x + w1 * J[a].y * J[c].y + w2 * J[a].z * J[c].z);
-    }
-  }
   // ---- control effort and slack penalty (ObjectiveManager.py:28-42) ----------
 #pragma unroll
   for (int j = 0; j < NU; j++) {
@@ -270,24 +269,18 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
     gf[NX] += 2.0 * ws * sl;
     Dg[NX] += 2.0 * ws;
   }
-
-  // ---- inequality rows ---------------------------------------------------------
-  double theta = 0.0, logsum = 0.0, rineq = 0.0, rcomp = 0.0, sumc = 0.0, minc = 1e300;
   const double rbody = (M.off_r_body >= 0) ? P(M.off_r_body) : 0.0;
 
-  // one row with value g (slack already added), gradient: gq over q (FK rows) or a
-  // single variable (var, sg); slack coupling when soft.
-  auto row_update = [&](int i, double g, bool is_fk, const double (&gq)[NQ], int var, double sg, bool soft) __attribute__((always_inline)) -> double {
+  // trial slack / multiplier of row i and their bookkeeping; returns sigma, ca, cb, lv
+  struct RowW { double sig, ca, cb, lv; };
+  auto row_core = [&](int i, double g, double tcv, double lcv, double dtv, double dlv) __attribute__((always_inline)) -> RowW {
     double tv, lv;
     if (first) {
       tv = g > kTMin ? g : kTMin;
       lv = mu / tv;
-    } else if (nostep) {
-      tv = tc[IDX(i, k, b)];
-      lv = lc[IDX(i, k, b)];
     } else {
-      tv = tc[IDX(i, k, b)] + alpha * W.dtt[IDX(i, k, b)];
-      lv = lc[IDX(i, k, b)] + adual * W.dlam[IDX(i, k, b)];
+      tv = tcv + am * dtv;
+      lv = lcv + dm * dlv;
     }
     tn[IDX(i, k, b)] = tv;
     ln[IDX(i, k, b)] = lv;
@@ -299,185 +292,181 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
     rcomp = fmax(rcomp, cmp);
     sumc += cmp;
     minc = fmin(minc, cmp);
-    const double sig = lv / tv, ca = lv * rg / tv, cb = 1.0 / tv;
-    if (is_fk) {
-#pragma unroll
-      for (int a = 0; a < NQ; a++) {
-        q0[a] += gq[a] * ca;
-        q1[a] += gq[a] * cb;
-        rs[a] -= gq[a] * lv;
-#pragma unroll
-        for (int c = a; c < NQ; c++) Qqq[a][c] += sig * gq[a] * gq[c];
-        if constexpr (NS > 0) { if (soft) cs[a] += sig * gq[a]; }
-      }
-    } else {
-      // single variable: statically indexed update through an unrolled select
-#pragma unroll
-      for (int j = 0; j < NV; j++) {
-        if (j == var) {
-          q0[j] += sg * ca;
-          q1[j] += sg * cb;
-          rs[j] -= sg * lv;
-          if (j < NQ) {
-#pragma unroll
-            for (int a = 0; a < NQ; a++) if (a == j) Qqq[a][a] += sig;
-          } else {
-            Dg[j] += sig;
-          }
-          if constexpr (NS > 0) { if (soft) cs[j] += sig * sg; }
-        }
-      }
-    }
-    if constexpr (NS > 0) {
-      if (soft) {
-        q0[NX] += ca;
-        q1[NX] += cb;
-        rs[NX] -= lv;
-        Dg[NX] += sig;
-      }
-    }
-    return lv;
+    const double it = 1.0 / tv;
+    return {lv * it, lv * rg * it, it, lv};
   };
 
-  // inverse-barrier objective on the first row of a module (constraint_avoidance.py:22-31)
-  auto avoid_update = [&](int mi, double h, bool is_fk, const double (&gq)[NQ], int var, double sg) __attribute__((always_inline)) -> double {
-    const double wi = P(M.off_wconstr + mi);
-    if (wi == 0.0) return 0.0;
-    const double cN = (double)M.N * wi;
-    if (!(h > 0.0)) bad = 1;
-    f += cN / h;
-    const double c1 = -cN / (h * h), c2 = 2.0 * cN / (h * h * h);
-    if (is_fk) {
+  // ---- kinematics, GoalReaching and the FK rows, slot by slot -------------------
+  Kin<C> kin;
+  {
+    double q[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; j++) q[j] = z[j];
+    kin.compute(M, T, q);
+  }
+  auto do_slot = [&](auto slc) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slc)::value;
+    if (SL >= T.nslots) return;
+    Vec3 J[NQ];
+    const Vec3 Pt = kin.template point<SL>(M, T, J);
+    if (SL == 0 && M.has_goal) {
+      // GoalReaching (goal_reaching.py:19-33), Gauss-Newton Hessian
+      const double e0 = Pt.x - P(M.off_goal), e1 = Pt.y - P(M.off_goal + 1), e2 = Pt.z - P(M.off_goal + 2);
+      const double w0 = P(M.off_wgoal), w1 = P(M.off_wgoal + 1), w2 = P(M.off_wgoal + 2);
+      f += w0 * e0 * e0 + w1 * e1 * e1 + w2 * e2 * e2;
 #pragma unroll
       for (int a = 0; a < NQ; a++) {
-        gf[a] += c1 * gq[a];
+        gf[a] += 2.0 * (w0 * e0 * J[a].x + w1 * e1 * J[a].y + w2 * e2 * J[a].z);
 #pragma unroll
-        for (int c = a; c < NQ; c++) Qqq[a][c] += c2 * gq[a] * gq[c];
+        for (int c = a; c < NQ; c++)
+          Qqq[a][c] += 2.0 * (w0 * J[a].x * J[c].x + w1 * J[a].y * J[c].y + w2 * J[a].z * J[c].z);
       }
-    } else {
+    }
+    for (int r = T.slot_row_begin[SL]; r < T.slot_row_begin[SL + 1]; r++) {
+      const int i = T.fk_row[r], kind = T.fk_kind[r], ob = T.fk_obst[r], mi = T.fk_mod[r];
+      // requests first, arithmetic after
+      const double tcv = tc[IDX(i, k, b)], lcv = lc[IDX(i, k, b)], dtv = dtp[IDX(i, k, b)], dlv = dlp[IDX(i, k, b)];
+      double gq[NQ];
+      double h, cinv = 0.0;
+      if (kind == ROW_RADIAL) {
+        // ||fk_l(q) - c_i|| - r_i - r_body (mpcBase.py:82-101)
+        const int o = M.off_obst + 4 * ob;
+        const Vec3 dv = {Pt.x - P(o), Pt.y - P(o + 1), Pt.z - P(o + 2)};
+        const double dist = sqrt(dot(dv, dv));
+        h = dist - P(o + 3) - rbody;
+        cinv = 1.0 / dist;
 #pragma unroll
-      for (int j = 0; j < NV; j++) {
-        if (j == var) {
-          gf[j] += c1 * sg;
-          if (j < NQ) {
+        for (int a = 0; a < NQ; a++) gq[a] = dot(dv, J[a]) * cinv;
+      } else if (kind == ROW_LINEAR) {
+        // |a.fk_l(q) + d| / ||a|| - r_body (LinearConstraints.py:25-40, utils.py:48-52)
+        const int o = M.off_lin + 4 * ob;
+        const Vec3 av = {P(o), P(o + 1), P(o + 2)};
+        const double nrm = sqrt(dot(av, av));
+        const double sd = dot(av, Pt) + P(o + 3);
+        const double sgn = sd < 0 ? -1.0 : 1.0;
+        h = fabs(sd) / nrm - rbody;
 #pragma unroll
-            for (int a = 0; a < NQ; a++) if (a == j) Qqq[a][a] += c2;
-          } else {
-            Dg[j] += c2;
+        for (int a = 0; a < NQ; a++) gq[a] = sgn * dot(av, J[a]) / nrm;
+      } else {
+        // ||fk_a(q) - fk_b(q)|| - 2 r_body (SelfCollisionAvoidanceConstraints.py:19-27)
+        const double dist = sqrt(dot(Pt, Pt));
+        h = dist - 2.0 * rbody;
+        cinv = 1.0 / dist;
+#pragma unroll
+        for (int a = 0; a < NQ; a++) gq[a] = dot(Pt, J[a]) * cinv;
+      }
+      double cw = 0.0;
+      if (M.has_avoid && T.fk_first[r]) {
+        // inverse-barrier objective N w_i / h on the first row of a module (constraint_avoidance.py:22-31)
+        const double wi = P(M.off_wconstr + mi);
+        if (wi != 0.0) {
+          const double cN = (double)M.N * wi;
+          if (!(h > 0.0)) bad = 1;
+          f += cN / h;
+          const double c1 = -cN / (h * h), c2 = 2.0 * cN / (h * h * h);
+          cw = cN / (h * h);
+#pragma unroll
+          for (int a = 0; a < NQ; a++) {
+            gf[a] += c1 * gq[a];
+#pragma unroll
+            for (int c = a; c < NQ; c++) Qqq[a][c] += c2 * gq[a] * gq[c];
           }
         }
       }
-    }
-    return cN / (h * h);
-  };
-
-  for (int i = 0; i < M.nh; i++) {
-    const int kind = M.row_kind[i];
-    const int ra = M.row_a[i], rb = M.row_b[i];
-    const int mi = M.row_mod[i];
-    const bool firstrow = M.has_avoid && (i == M.mod_row0[mi]);
-    double gq[NQ];
-#pragma unroll
-    for (int a = 0; a < NQ; a++) gq[a] = 0.0;
-    double h = 0.0;
-    int var = -1;
-    double sg = 0.0;
-    bool is_fk = true;
-    Vec3 Jc[NQ];  // Jacobian of the point (or point difference) the row measures
-    double cinv = 0.0;
-#pragma unroll
-    for (int a = 0; a < NQ; a++) Jc[a] = {0, 0, 0};
-    if (kind == ROW_RADIAL) {
-      // ||fk_l(q) - c_i|| - r_i - r_body (mpcBase.py:82-101)
-      const Vec3 pl = kin.pos(M, ra);
-      Vec3 J[NQ];
-      kin.jac(M, ra, pl, J);
-      const int o = M.off_obst + 4 * rb;
-      const Vec3 dv = {pl.x - P(o), pl.y - P(o + 1), pl.z - P(o + 2)};
-      const double dist = sqrt(dot(dv, dv));
-      h = dist - P(o + 3) - rbody;
-      const double inv = 1.0 / dist;
-      cinv = inv;
-#pragma unroll
-      for (int a = 0; a < NQ; a++) { gq[a] = dot(dv, J[a]) * inv; Jc[a] = J[a]; }
-    } else if (kind == ROW_LINEAR) {
-      // |a.fk_l(q) + d| / ||a|| - r_body (LinearConstraints.py:25-40, utils.py:48-52)
-      const Vec3 pl = kin.pos(M, ra);
-      Vec3 J[NQ];
-      kin.jac(M, ra, pl, J);
-      const int o = M.off_lin + 4 * rb;
-      const Vec3 av = {P(o), P(o + 1), P(o + 2)};
-      const double nrm = sqrt(dot(av, av));
-      const double sd = dot(av, pl) + P(o + 3);
-      const double sgn = sd < 0 ? -1.0 : 1.0;
-      h = fabs(sd) / nrm - rbody;
-#pragma unroll
-      for (int a = 0; a < NQ; a++) gq[a] = sgn * dot(av, J[a]) / nrm;
-    } else if (kind == ROW_SELF) {
-      // ||fk_a(q) - fk_b(q)|| - 2 r_body (SelfCollisionAvoidanceConstraints.py:19-27)
-      const Vec3 pa = kin.pos(M, ra), pb = kin.pos(M, rb);
-      Vec3 Ja[NQ], Jb[NQ];
-      kin.jac(M, ra, pa, Ja);
-      kin.jac(M, rb, pb, Jb);
-      const Vec3 dv = pa - pb;
-      const double dist = sqrt(dot(dv, dv));
-      h = dist - 2.0 * rbody;
-      const double inv = 1.0 / dist;
-      cinv = inv;
-#pragma unroll
-      for (int a = 0; a < NQ; a++) { Jc[a] = Ja[a] - Jb[a]; gq[a] = dot(dv, Jc[a]) * inv; }
-    } else {
-      // joint / velocity / input limits: sg * (z_var - limit)
-      is_fk = false;
-      var = ra;
-      sg = (double)rb;
-      double zv = 0.0;
-#pragma unroll
-      for (int j = 0; j < NV; j++) if (j == var) zv = z[j];
-      h = sg * (zv - P(M.row_poff[i]));
-    }
-    double cw = 0.0;
-    if (firstrow) cw = avoid_update(mi, h, is_fk, gq, var, sg);
-    double g = h;
-    if constexpr (NS > 0) g += sl;  // softened rows (intended InequalityManager.py:29-32)
-    W.grow[IDX(i, k, b)] = g;
-    if (is_fk) {
-      const int fi = M.row_fk[i];
+      double g = h;
+      if constexpr (NS > 0) g += sl;  // softened rows (intended InequalityManager.py:29-32)
+      W.grow[IDX(i, k, b)] = g;
+      const int fi = T.fk_idx[r];
 #pragma unroll
       for (int a = 0; a < NQ; a++) W.Jq[IDX(fi * NQ + a, k, b)] = gq[a];
-    }
-    const double lvr = row_update(i, g, is_fk, gq, var, sg, NS > 0);
-    if constexpr (C::CURV) {
-      // exact Hessian of the distance rows when the kinematics are affine in q:
-      // grad^2 h = (J^T J - g g^T) / dist, weighted by the multiplier and the inverse-barrier term
-      if (M.use_curv && (kind == ROW_RADIAL || kind == ROW_SELF)) {
-        const double wgt = (lvr + cw) * cinv;
+      const RowW rw = row_core(i, g, tcv, lcv, dtv, dlv);
 #pragma unroll
-        for (int a = 0; a < NQ; a++)
+      for (int a = 0; a < NQ; a++) {
+        q0[a] += gq[a] * rw.ca;
+        q1[a] += gq[a] * rw.cb;
+        rs[a] -= gq[a] * rw.lv;
 #pragma unroll
-          for (int c = a; c < NQ; c++) Cqq[a][c] += wgt * (dot(Jc[a], Jc[c]) - gq[a] * gq[c]);
+        for (int c = a; c < NQ; c++) Qqq[a][c] += rw.sig * gq[a] * gq[c];
+        if constexpr (NS > 0) cs[a] += rw.sig * gq[a];
+      }
+      if constexpr (NS > 0) {
+        q0[NX] += rw.ca;
+        q1[NX] += rw.cb;
+        rs[NX] -= rw.lv;
+        Dg[NX] += rw.sig;
+      }
+      if constexpr (C::CURV) {
+        // exact Hessian of the distance rows when the kinematics are affine in q:
+        // grad^2 h = (J^T J - g g^T) / dist, weighted by the multiplier and the inverse-barrier term
+        if (M.use_curv && kind != ROW_LINEAR) {
+          const double wgt = (rw.lv + cw) * cinv;
+#pragma unroll
+          for (int a = 0; a < NQ; a++)
+#pragma unroll
+            for (int c = a; c < NQ; c++) Cqq[a][c] += wgt * (dot(J[a], J[c]) - gq[a] * gq[c]);
+        }
       }
     }
-  }
-  // simple bounds (mpcModel.py:91-104): lower rows then upper rows, never softened
-  {
-    double gq[NQ];
+  };
+  do_slot(std::integral_constant<int, 0>{});
+  do_slot(std::integral_constant<int, 1>{});
+  do_slot(std::integral_constant<int, 2>{});
+  do_slot(std::integral_constant<int, 3>{});
+
+  // ---- single-variable rows: limits (general rows) and simple bounds, by variable ----
 #pragma unroll
-    for (int a = 0; a < NQ; a++) gq[a] = 0.0;
-    int i = M.nh;
-    for (int r = 0; r < M.nlb; r++, i++) {
-      const int var = M.lb_var[r];
-      double zv = 0.0;
+  for (int j = 0; j < NV; j++) {
+    // unconditional, clamped requests for the (up to) four rows of variable j
+    double tcv[kVarRows], lcv[kVarRows], dtv[kVarRows], dlv[kVarRows], lim[kVarRows];
 #pragma unroll
-      for (int j = 0; j < NV; j++) if (j == var) zv = z[j];
-      row_update(i, zv - M.lb_val[r], false, gq, var, 1.0, false);
+    for (int u = 0; u < kVarRows; u++) {
+      const int i = T.v_row[j][u];
+      const int ii = i >= 0 ? i : 0;
+      const int po = T.v_poff[j][u];
+      tcv[u] = tc[IDX(ii, k, b)];
+      lcv[u] = lc[IDX(ii, k, b)];
+      dtv[u] = dtp[IDX(ii, k, b)];
+      dlv[u] = dlp[IDX(ii, k, b)];
+      const double pl = pp[IDX(po >= 0 ? po : 0, k, b)];
+      lim[u] = po >= 0 ? pl : T.v_val[j][u];
     }
-    for (int r = 0; r < M.nub; r++, i++) {
-      const int var = M.ub_var[r];
-      double zv = 0.0;
 #pragma unroll
-      for (int j = 0; j < NV; j++) if (j == var) zv = z[j];
-      row_update(i, M.ub_val[r] - zv, false, gq, var, -1.0, false);
+    for (int u = 0; u < kVarRows; u++) {
+      const int i = T.v_row[j][u];
+      if (i < 0) continue;  // uniform
+      const double sg = (double)T.v_sgn[j][u];
+      const bool soft = (NS > 0) && T.v_soft[j][u];
+      const double h = sg * (z[j] - lim[u]);
+      if (M.has_avoid && T.v_first[j][u]) {
+        const double wi = P(M.off_wconstr + T.v_mod[j][u]);
+        if (wi != 0.0) {
+          const double cN = (double)M.N * wi;
+          if (!(h > 0.0)) bad = 1;
+          f += cN / h;
+          gf[j] += -cN / (h * h) * sg;
+          const double c2 = 2.0 * cN / (h * h * h);
+          if (j < NQ) Qqq[j < NQ ? j : 0][j < NQ ? j : 0] += c2;
+          else Dg[j] += c2;
+        }
+      }
+      double g = h;
+      if constexpr (NS > 0) { if (soft) g += sl; }
+      if (T.v_poff[j][u] >= 0) W.grow[IDX(i, k, b)] = g;  // general rows keep their value for k_step
+      const RowW rw = row_core(i, g, tcv[u], lcv[u], dtv[u], dlv[u]);
+      q0[j] += sg * rw.ca;
+      q1[j] += sg * rw.cb;
+      rs[j] -= sg * rw.lv;
+      if (j < NQ) Qqq[j < NQ ? j : 0][j < NQ ? j : 0] += rw.sig;
+      else Dg[j] += rw.sig;
+      if constexpr (NS > 0) {
+        if (soft) {
+          cs[j] += rw.sig * sg;
+          q0[NX] += rw.ca;
+          q1[NX] += rw.cb;
+          rs[NX] -= rw.lv;
+          Dg[NX] += rw.sig;
+        }
+      }
     }
   }
 
@@ -525,9 +514,7 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const Ws W, con
     }
 #pragma unroll
     for (int j = 0; j < NX; j++) {
-      double xk1 = zc[IDX(j, k + 1, b)];
-      if (!nostep) xk1 += alpha * W.dz[IDX(j, k + 1, b)];
-      const double r = xn[j] - xk1;
+      const double r = xn[j] - xk1[j];
       W.rc[IDX(j, k, b)] = r;
       req = fmax(req, fabs(r));
       theta += fabs(r);
@@ -664,11 +651,9 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
     // null pass: same point, the step is recomputed below with the Gauss-Newton blocks
     W.redo[b] = 0;
   } else {
-    double gphi = 0.0, a0 = 1.0;
-    for (int k = 0; k < N; k++) {
-      gphi += W.gphi[(size_t)k * W.Bp + b];
-      a0 = fmin(a0, W.ap[(size_t)k * W.Bp + b]);
-    }
+    double gphi = 0.0;
+    for (int k = 0; k < N; k++) gphi += W.gphi[(size_t)k * W.Bp + b];
+    const double a0 = __longlong_as_double((long long)W.amin_p[b]);
     int ls = W.ls[b];
     double rho = W.rho[b], phi0 = W.phi0[b], Dd = W.Dd[b];
     if (ls == 0) {
@@ -1129,6 +1114,8 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
   }
 #undef UP
   W.newstep[b] = 1;
+  W.amin_p[b] = (unsigned long long)__double_as_longlong(1.0);  // k_step takes the minima next
+  W.amin_d[b] = (unsigned long long)__double_as_longlong(1.0);
   atomicAdd(&W.active_hist[pass], 1);
 }
 
@@ -1136,66 +1123,83 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
 // k_step: slack / multiplier steps and step-length partials, stage parallel
 // ===========================================================================
 template <class C>
-__global__ __launch_bounds__(256) void k_step(const DevModel M, const Ws W, const int B) {
+__global__ __launch_bounds__(256) void k_step(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
+                                              const int B) {
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NV = C::NV;
+  const DevTables &T = *Tp;
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int b = gid % W.Bp;
   const int k = gid / W.Bp;
   if (b >= B || k >= M.N) return;
   if (W.status[b] != ST_ACTIVE || !W.newstep[b]) return;
   const int cur = W.cur[b];
-  const double *zc = W.z[cur], *tc = W.t[cur], *lc = W.lam[cur];
+  const double *__restrict__ zc = W.z[cur];
+  const double *__restrict__ tc = W.t[cur];
+  const double *__restrict__ lc = W.lam[cur];
+  const double *__restrict__ grow = W.grow;
+  const double *__restrict__ Jq = W.Jq;
+  double *__restrict__ dto = W.dtt;
+  double *__restrict__ dlo = W.dlam;
   const double mu = W.mu[b];
-  double dz[NV], z[NV];
-  double gphi = 0.0;
+  double dz[NV], z[NV], gfv[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) {
     dz[j] = W.dz[IDX(j, k, b)];
     z[j] = zc[IDX(j, k, b)];
-    gphi += W.gfa[IDX(j, k, b)] * dz[j];
+    gfv[j] = W.gfa[IDX(j, k, b)];
   }
+  double gphi = 0.0;
+#pragma unroll
+  for (int j = 0; j < NV; j++) gphi += gfv[j] * dz[j];
   double ap = 1.0, ad = 1.0;
-  auto row = [&](int i, double gdz, double g) __attribute__((always_inline)) {
-    const double tv = tc[IDX(i, k, b)], lv = lc[IDX(i, k, b)];
+  auto row = [&](int i, double gdz, double g, double tv, double lv) __attribute__((always_inline)) {
     const double dt = gdz + (g - tv);
     const double dl = (mu - tv * lv - lv * dt) / tv;
-    W.dtt[IDX(i, k, b)] = dt;
-    W.dlam[IDX(i, k, b)] = dl;
+    dto[IDX(i, k, b)] = dt;
+    dlo[IDX(i, k, b)] = dl;
     if (dt < 0) ap = fmin(ap, -kTau * tv / dt);
     if (dl < 0) ad = fmin(ad, -kTau * lv / dl);
     gphi -= mu * dt / tv;
   };
-  auto pick = [&](const double (&v)[NV], int var) __attribute__((always_inline)) {
-    double r = 0.0;
+  // FK rows
+  for (int r = 0; r < T.nfkrows; r++) {
+    const int i = T.fk_row[r], fi = T.fk_idx[r];
+    const double g = grow[IDX(i, k, b)], tv = tc[IDX(i, k, b)], lv = lc[IDX(i, k, b)];
+    double jq[NQ];
 #pragma unroll
-    for (int j = 0; j < NV; j++) if (j == var) r = v[j];
-    return r;
-  };
-  for (int i = 0; i < M.nh; i++) {
-    const double g = W.grow[IDX(i, k, b)];
-    double gdz;
-    if (M.row_kind[i] != ROW_SINGLE) {
-      const int fi = M.row_fk[i];
-      gdz = 0.0;
+    for (int a = 0; a < NQ; a++) jq[a] = Jq[IDX(fi * NQ + a, k, b)];
+    double gdz = 0.0;
 #pragma unroll
-      for (int a = 0; a < NQ; a++) gdz += W.Jq[IDX(fi * NQ + a, k, b)] * dz[a];
-    } else {
-      gdz = (double)M.row_b[i] * pick(dz, M.row_a[i]);
-    }
+    for (int a = 0; a < NQ; a++) gdz += jq[a] * dz[a];
     if constexpr (NS > 0) gdz += dz[NX];
-    row(i, gdz, g);
+    row(i, gdz, g, tv, lv);
   }
-  int i = M.nh;
-  for (int r = 0; r < M.nlb; r++, i++) {
-    const int var = M.lb_var[r];
-    row(i, pick(dz, var), pick(z, var) - M.lb_val[r]);
+  // single-variable rows, by variable (unconditional clamped requests, see k_sweep)
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    double tv[kVarRows], lv[kVarRows], gv[kVarRows];
+#pragma unroll
+    for (int u = 0; u < kVarRows; u++) {
+      const int i = T.v_row[j][u];
+      const int ii = i >= 0 ? i : 0;
+      const bool general = T.v_poff[j][u] >= 0;
+      tv[u] = tc[IDX(ii, k, b)];
+      lv[u] = lc[IDX(ii, k, b)];
+      const double gl = grow[IDX(general ? ii : 0, k, b)];
+      gv[u] = general ? gl : (double)T.v_sgn[j][u] * (z[j] - T.v_val[j][u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kVarRows; u++) {
+      const int i = T.v_row[j][u];
+      if (i < 0) continue;
+      double gdz = (double)T.v_sgn[j][u] * dz[j];
+      if constexpr (NS > 0) { if (T.v_soft[j][u]) gdz += dz[NX]; }
+      row(i, gdz, gv[u], tv[u], lv[u]);
+    }
   }
-  for (int r = 0; r < M.nub; r++, i++) {
-    const int var = M.ub_var[r];
-    row(i, -pick(dz, var), M.ub_val[r] - pick(z, var));
-  }
-  W.ap[(size_t)k * W.Bp + b] = ap;
-  W.ad[(size_t)k * W.Bp + b] = ad;
+  // partial minima -> per-instance step lengths (min is order independent: deterministic)
+  atomicMin(&W.amin_p[b], (unsigned long long)__double_as_longlong(ap));
+  atomicMin(&W.amin_d[b], (unsigned long long)__double_as_longlong(ad));
   W.gphi[(size_t)k * W.Bp + b] = gphi;
 }
 
@@ -1224,6 +1228,8 @@ static const char *kKernelNames[RMPC_NUM_KERNELS] = {"k_pack", "k_sweep", "k_ric
 struct rmpc_handle {
   rmpc_desc desc;
   DevModel M;
+  DevTables T;
+  DevTables *d_T = nullptr;
   Ws W;
   int device = 0;
   int max_batch = 0;
@@ -1250,6 +1256,67 @@ struct rmpc_handle {
   double prof_bytes[RMPC_NUM_KERNELS] = {0};     // accumulated algorithmic bytes of the profiled launches
   std::vector<int> h_hist;
 };
+
+// Row tables in device memory (DevTables): kinematic slots with their FK rows, and the
+// single-variable rows grouped by variable.
+static int build_tables(const rmpc_desc &d, const DevModel &M, DevTables &T, std::string &err) {
+  memset(&T, 0, sizeof T);
+  for (int s = 0; s < kMaxSlots; s++) { T.slot_fa[s] = -1; T.slot_fb[s] = -1; }
+  for (int j = 0; j < RMPC_NV_MAX; j++)
+    for (int u = 0; u < kVarRows; u++) { T.v_row[j][u] = -1; T.v_poff[j][u] = -1; T.v_mod[j][u] = -1; }
+  auto slot_of = [&](int fa, int fb) -> int {
+    for (int s = 0; s < T.nslots; s++)
+      if (T.slot_fa[s] == fa && T.slot_fb[s] == fb) return s;
+    if (T.nslots >= kMaxSlots) return -1;
+    T.slot_fa[T.nslots] = fa; T.slot_fb[T.nslots] = fb;
+    return T.nslots++;
+  };
+  if (d.has_goal && slot_of(d.end_frame, -1) != 0) { err = "slot table"; return -1; }
+  // FK rows with their slots, then sorted by slot
+  struct FkRow { int row, kind, obst, mod, first, idx, slot; };
+  std::vector<FkRow> rows;
+  for (int i = 0; i < M.nh; i++) {
+    if (M.row_kind[i] == ROW_SINGLE) continue;
+    const int fb = (M.row_kind[i] == ROW_SELF) ? M.row_b[i] : -1;
+    const int s = slot_of(M.row_a[i], fb);
+    if (s < 0) { err = "more than 4 distinct collision points (links / link pairs / end link)"; return -1; }
+    rows.push_back({i, M.row_kind[i], M.row_kind[i] == ROW_SELF ? 0 : M.row_b[i], M.row_mod[i],
+                    i == M.mod_row0[M.row_mod[i]] ? 1 : 0, M.row_fk[i], s});
+  }
+  if ((int)rows.size() > kMaxFkRows) { err = "too many distance rows"; return -1; }
+  int r = 0;
+  for (int s = 0; s < kMaxSlots; s++) {
+    T.slot_row_begin[s] = r;
+    for (const FkRow &fr : rows)
+      if (fr.slot == s) {
+        T.fk_row[r] = (int16_t)fr.row; T.fk_kind[r] = (int8_t)fr.kind; T.fk_obst[r] = (int8_t)fr.obst;
+        T.fk_mod[r] = (int8_t)fr.mod; T.fk_first[r] = (int8_t)fr.first; T.fk_idx[r] = (int16_t)fr.idx;
+        r++;
+      }
+  }
+  T.slot_row_begin[kMaxSlots] = r;
+  T.nfkrows = r;
+  // single-variable rows
+  auto add_var_row = [&](int var, int row, int sgn, int poff, double val, int soft, int mod, int firstrow) -> bool {
+    for (int u = 0; u < kVarRows; u++)
+      if (T.v_row[var][u] < 0) {
+        T.v_row[var][u] = (int16_t)row; T.v_sgn[var][u] = (int8_t)sgn; T.v_poff[var][u] = (int16_t)poff;
+        T.v_val[var][u] = val; T.v_soft[var][u] = (int8_t)soft; T.v_mod[var][u] = (int8_t)mod;
+        T.v_first[var][u] = (int8_t)firstrow;
+        return true;
+      }
+    return false;
+  };
+  bool ok = true;
+  for (int i = 0; i < M.nh && ok; i++)
+    if (M.row_kind[i] == ROW_SINGLE)
+      ok = add_var_row(M.row_a[i], i, M.row_b[i], M.row_poff[i], 0.0, 1, M.row_mod[i], i == M.mod_row0[M.row_mod[i]] ? 1 : 0);
+  int i = M.nh;
+  for (int q = 0; q < M.nlb && ok; q++, i++) ok = add_var_row(M.lb_var[q], i, +1, -1, M.lb_val[q], 0, -1, 0);
+  for (int q = 0; q < M.nub && ok; q++, i++) ok = add_var_row(M.ub_var[q], i, -1, -1, M.ub_val[q], 0, -1, 0);
+  if (!ok) { err = "more than 4 limit / bound rows on one variable"; return -1; }
+  return 0;
+}
 
 static int variant_of(const rmpc_desc &d) {
   // 0..5: (chain n=3, chain n=7, diffdrive) x (ns = 0, 1)
@@ -1452,9 +1519,9 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   W.kff = c.take<double>(S * M.nw);
   W.Pst = c.take<double>(S * (M.nx * (M.nx + 1) / 2 + M.nx));
   W.part = c.take<double>(S * P_COUNT);
-  W.ap = c.take<double>(S);
-  W.ad = c.take<double>(S);
   W.gphi = c.take<double>(S);
+  W.amin_p = c.take<unsigned long long>(Bp);
+  W.amin_d = c.take<unsigned long long>(Bp);
   double **per[] = {&W.mu, &W.rho, &W.phi0, &W.Dd, &W.fcur, &W.thcur, &W.logcur,
                     &W.res_stat, &W.res_eq, &W.res_ineq, &W.res_comp, &W.obj};
   for (auto pp : per) *pp = c.take<double>(Bp);
@@ -1473,7 +1540,7 @@ static void fill_lane_bytes(rmpc_handle *h, int B) {
   const DevModel &M = h->M;
   const int nq2 = M.n * (M.n + 1) / 2;
   const int64_t dd = (M.robot == RMPC_ROBOT_DIFFDRIVE) ? 35 : 0;
-  const int64_t sweep_rd = M.nv * 2 + M.m * 4 + M.nx * 4 + M.npar + M.nx * 2 + 2 * M.N;
+  const int64_t sweep_rd = M.nv * 2 + M.m * 4 + M.nx * 4 + M.npar + M.nx * 2 + 2;
   const int64_t sweep_wr = M.nv + 2 * M.m + M.nx + nq2 + (M.use_curv ? nq2 : 0) + (M.nv - M.n) + (M.ns ? M.nv : 0) +
                            3 * M.nv + M.nh + M.nfk * M.n + M.nx + dd + P_COUNT;
   const int64_t np2 = M.nx * (M.nx + 1) / 2 + M.nx;
@@ -1482,7 +1549,7 @@ static void fill_lane_bytes(rmpc_handle *h, int B) {
                          (M.nw * M.nx + M.nw) + np2;
   const int64_t ric_wr = (M.nw * M.nx + M.nw) + np2 + M.nv + M.nx;
   const int64_t step_rd = 3 * M.nv + 2 * M.m + M.nh + M.nfk * M.n;
-  const int64_t step_wr = 2 * M.m + 3;
+  const int64_t step_wr = 2 * M.m + 3;  // two of the three are atomic minima
   h->lane_bytes[K_PACK] = 16 * ((int64_t)B * (M.nx + (int64_t)M.N * (M.nv + M.npar)));
   h->lane_bytes[K_SWEEP] = 8 * (sweep_rd + sweep_wr);
   h->lane_bytes[K_RICCATI] = 8 * (int64_t)M.N * (ric_rd + ric_wr);
@@ -1493,9 +1560,9 @@ static void fill_lane_bytes(rmpc_handle *h, int B) {
 template <class C>
 static void launch_pass(rmpc_handle *h, int B, int first, int pass, hipStream_t st, int which) {
   const int lanes = h->Bp * h->M.N;
-  if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->W, B, first);
+  if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, h->W, B, first);
   else if (which == K_RICCATI) hipLaunchKernelGGL((k_riccati<C>), dim3((B + 63) / 64), dim3(64), 0, st, h->M, h->W, B, first, pass);
-  else hipLaunchKernelGGL((k_step<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->W, B);
+  else hipLaunchKernelGGL((k_step<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, h->W, B);
 }
 
 static void launch_variant(rmpc_handle *h, int B, int first, int pass, hipStream_t st, int which) {
@@ -1614,6 +1681,8 @@ int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch) {
   DevModel M;
   std::string err;
   if (build_model(*desc, M, err) != 0) { g_err = err; return -1; }
+  DevTables T;
+  if (build_tables(*desc, M, T, err) != 0) { g_err = err; return -1; }
   Ws W;
   const int Bp = (max_batch + 63) / 64 * 64;
   return (int64_t)carve(M, Bp, passes_cap(M), nullptr, W);
@@ -1627,6 +1696,7 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   h->desc = *desc;
   std::string err;
   if (build_model(*desc, h->M, err) != 0) { delete h; return fail("invalid descriptor: " + err); }
+  if (build_tables(*desc, h->M, h->T, err) != 0) { delete h; return fail("invalid descriptor: " + err); }
   h->variant = variant_of(*desc);
   if (h->variant < 0) { delete h; return fail("no kernel variant for this robot (supported: chain n=3, chain n=7, diff-drive n=3)"); }
   int ndev = 0;
@@ -1644,6 +1714,9 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   if (e != hipSuccess) { delete h; return fail(std::string("hipMalloc workspace: ") + hipGetErrorString(e)); }
   (void)hipMemset(h->ws_base, 0, h->ws_bytes);
   carve(h->M, h->Bp, h->max_passes, h->ws_base, h->W);
+  e = hipMalloc((void **)&h->d_T, sizeof(DevTables));
+  if (e == hipSuccess) e = hipMemcpy(h->d_T, &h->T, sizeof(DevTables), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(h->ws_base); delete h; return fail(std::string("row tables: ") + hipGetErrorString(e)); }
   (void)hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   (void)hipHostMalloc((void **)&h->h_active, sizeof(int), hipHostMallocDefault);
   *out = h;
@@ -1654,7 +1727,7 @@ void rmpc_destroy(rmpc_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void *bufs[] = {h->ws_base, h->d_xinit, h->d_x0, h->d_params, h->d_zout, h->d_kkt, h->d_obj, h->d_exit, h->d_iters};
+  void *bufs[] = {h->ws_base, (void *)h->d_T, h->d_xinit, h->d_x0, h->d_params, h->d_zout, h->d_kkt, h->d_obj, h->d_exit, h->d_iters};
   for (void *p : bufs) (void)hipFree(p);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->h_active) (void)hipHostFree(h->h_active);

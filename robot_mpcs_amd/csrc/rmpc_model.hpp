@@ -57,6 +57,30 @@ struct DevModel {
   double acc_obj_tol;
 };
 
+// Row tables that are too large for the kernel argument live in device memory; they are
+// uniform, so the kernels read them through the scalar cache.
+constexpr int kMaxSlots = 4;   // distinct points (frame, or frame pair) the FK rows and the goal refer to
+constexpr int kMaxFkRows = 40;
+constexpr int kVarRows = 4;    // single-variable rows per variable: limit lower/upper, bound lower/upper
+struct DevTables {
+  // kinematic slots: slot 0 is the goal's end frame when GoalReaching is present
+  int nslots;
+  int slot_fa[kMaxSlots], slot_fb[kMaxSlots];        // frame A, frame B (-1: single frame)
+  int slot_row_begin[kMaxSlots + 1];                 // FK rows sorted by slot
+  int nfkrows;
+  int16_t fk_row[kMaxFkRows];                        // storage index of the row (YAML order)
+  int8_t fk_kind[kMaxFkRows], fk_obst[kMaxFkRows], fk_mod[kMaxFkRows], fk_first[kMaxFkRows];
+  int16_t fk_idx[kMaxFkRows];                        // index among the FK rows (Jq storage)
+  // rows that depend on one variable only, grouped by variable
+  int16_t v_row[RMPC_NV_MAX][kVarRows];              // storage index or -1
+  int8_t v_sgn[RMPC_NV_MAX][kVarRows];               // +1: z - limit, -1: limit - z
+  int16_t v_poff[RMPC_NV_MAX][kVarRows];             // parameter offset of the limit, -1: constant bound
+  int8_t v_soft[RMPC_NV_MAX][kVarRows];              // general row (softened when ns = 1)
+  int8_t v_mod[RMPC_NV_MAX][kVarRows];               // owning module, -1 for simple bounds
+  int8_t v_first[RMPC_NV_MAX][kVarRows];             // first row of its module (inverse-barrier objective)
+  double v_val[RMPC_NV_MAX][kVarRows];               // constant bound value
+};
+
 struct Vec3 {
   double x, y, z;
 };
@@ -82,18 +106,23 @@ struct Cfg {
 };
 
 // ---------------------------------------------------------------------------
-// Kinematics: one pass over the chain, positions of every frame plus what the
-// analytic position Jacobian needs (joint origins and world axes).
+// Kinematics: one pass over the chain.  Everything is indexed by unrolled loop
+// counters only (a uniform *runtime* index into a register array is turned into
+// scratch memory by the compiler), so the points the rows need are captured
+// into "slots" while the chain is walked.
 // ---------------------------------------------------------------------------
 template <class C>
 struct Kin {
-  Vec3 fpos[C::ROBOT == RMPC_ROBOT_CHAIN ? C::NQ : 1];
-  Vec3 oj[C::ROBOT == RMPC_ROBOT_CHAIN ? C::NQ : 1];
-  Vec3 aj[C::ROBOT == RMPC_ROBOT_CHAIN ? C::NQ : 1];
-  double c, s, qx, qy;  // diff-drive base pose
+  static constexpr bool CHAIN = (C::ROBOT == RMPC_ROBOT_CHAIN);
+  Vec3 oj[CHAIN ? C::NQ : 1];   // joint origins
+  Vec3 aj[CHAIN ? C::NQ : 1];   // joint axes (world)
+  Vec3 pa[kMaxSlots], pb[kMaxSlots];  // positions of frame A / frame B of every slot
+  double c, s, qx, qy;          // diff-drive base pose
 
-  __device__ __forceinline__ void compute(const DevModel &M, const double (&q)[C::NQ]) {
-    if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
+  __device__ __forceinline__ void compute(const DevModel &M, const DevTables &T, const double (&q)[C::NQ]) {
+#pragma unroll
+    for (int sl = 0; sl < kMaxSlots; sl++) { pa[sl] = {0, 0, 0}; pb[sl] = {0, 0, 0}; }
+    if constexpr (CHAIN) {
       double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
       Vec3 o = {0, 0, 0};
 #pragma unroll
@@ -117,48 +146,66 @@ struct Kin {
           o.y += a.y * q[j];
           o.z += a.z * q[j];
         }
-        fpos[j] = o;
+#pragma unroll
+        for (int sl = 0; sl < kMaxSlots; sl++) {
+          if (T.slot_fa[sl] == j) pa[sl] = o;
+          if (T.slot_fb[sl] == j) pb[sl] = o;
+        }
       }
     } else {
       c = cos(q[2]);
       s = sin(q[2]);
       qx = q[0];
       qy = q[1];
-    }
-  }
-
-  // position of frame f (uniform f)
-  __device__ __forceinline__ Vec3 pos(const DevModel &M, int f) const {
-    if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
-      Vec3 r = fpos[0];
 #pragma unroll
-      for (int j = 1; j < C::NQ; j++)
-        if (f == j) r = fpos[j];
-      return r;
-    } else {
-      const double *o = M.dd_off[f];
-      return {qx + c * o[0] - s * o[1], qy + s * o[0] + c * o[1], o[2]};
+      for (int sl = 0; sl < kMaxSlots; sl++) {
+        if (sl < T.nslots) {
+          const double *o = M.dd_off[T.slot_fa[sl]];
+          pa[sl] = {qx + c * o[0] - s * o[1], qy + s * o[0] + c * o[1], o[2]};
+          if (T.slot_fb[sl] >= 0) {
+            const double *ob = M.dd_off[T.slot_fb[sl]];
+            pb[sl] = {qx + c * ob[0] - s * ob[1], qy + s * ob[0] + c * ob[1], ob[2]};
+          }
+        }
+      }
     }
   }
 
-  // d pos(f) / d q_d for every d
-  __device__ __forceinline__ void jac(const DevModel &M, int f, Vec3 pf, Vec3 (&J)[C::NQ]) const {
-    if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
+  // Point of slot sl (static sl): P = pos(A) - pos(B) (B absent: pos(A)) and dP/dq.
+  template <int SL>
+  __device__ __forceinline__ Vec3 point(const DevModel &M, const DevTables &T, Vec3 (&J)[C::NQ]) const {
+    const int fa = T.slot_fa[SL], fb = T.slot_fb[SL];
+    Vec3 P = pa[SL];
+    if constexpr (CHAIN) {
 #pragma unroll
       for (int d = 0; d < C::NQ; d++) {
         Vec3 col = {0, 0, 0};
-        if (d <= f) {
-          if (M.joint_type[d] == RMPC_JOINT_REVOLUTE) col = cross(aj[d], pf - oj[d]);
+        if (d <= fa) {
+          if (M.joint_type[d] == RMPC_JOINT_REVOLUTE) col = cross(aj[d], pa[SL] - oj[d]);
           else if (M.joint_type[d] == RMPC_JOINT_PRISMATIC) col = aj[d];
+        }
+        if (fb >= 0 && d <= fb) {
+          Vec3 cb = {0, 0, 0};
+          if (M.joint_type[d] == RMPC_JOINT_REVOLUTE) cb = cross(aj[d], pb[SL] - oj[d]);
+          else if (M.joint_type[d] == RMPC_JOINT_PRISMATIC) cb = aj[d];
+          col = col - cb;
         }
         J[d] = col;
       }
     } else {
-      const double *o = M.dd_off[f];
+      const double *o = M.dd_off[fa];
       J[0] = {1, 0, 0};
       J[1] = {0, 1, 0};
       J[2] = {-s * o[0] - c * o[1], c * o[0] - s * o[1], 0};
+      if (fb >= 0) {
+        const double *ob = M.dd_off[fb];
+        J[0] = {0, 0, 0};
+        J[1] = {0, 0, 0};
+        J[2] = {J[2].x - (-s * ob[0] - c * ob[1]), J[2].y - (c * ob[0] - s * ob[1]), 0};
+      }
     }
+    if (fb >= 0) P = P - pb[SL];
+    return P;
   }
 
  private:
