@@ -482,8 +482,8 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
 #define ORC_ARMIJO 1e-4
 #define ORC_MU_DIVERGED 1e12
 #define ORC_CURV_MU 1e-2    /* curvature terms only once the barrier parameter is this small */
-#define ORC_LS_CURV 3       /* trials granted to a step computed with constraint curvature */
-#define ORC_CURV_FAIL_MAX 5 /* consecutive curvature-step failures before latching Gauss-Newton */
+#define ORC_LS_CURV 2       /* trials granted to a step computed with constraint curvature */
+#define ORC_CURV_FAIL_MAX 2 /* consecutive curvature-step failures before latching Gauss-Newton */
 #define ORC_ACC_FEAS 1e-6   /* ... feasibility / complementarity level */
 #define ORC_TRACE_W 8
 

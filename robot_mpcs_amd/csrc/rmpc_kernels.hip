@@ -43,8 +43,8 @@ constexpr int kLsMax = 25;
 constexpr double kArmijo = 1e-4;
 constexpr double kMuDiverged = 1e12;
 constexpr double kCurvMu = 1e-2; // curvature terms only once the barrier parameter is this small
-constexpr int kLsCurv = 3;        // trials granted to a step computed with constraint curvature
-constexpr int kCurvFailMax = 5;   // consecutive curvature-step failures before Gauss-Newton is latched
+constexpr int kLsCurv = 2;        // trials granted to a step computed with constraint curvature
+constexpr int kCurvFailMax = 2;   // consecutive curvature-step failures before Gauss-Newton is latched
 constexpr double kAccFeas = 1e-6; // acceptable termination: feasibility / complementarity level
 
 enum Status : int { ST_ACTIVE = 100 };
@@ -59,6 +59,7 @@ struct Ws {
   double *dz, *dtt, *dlam, *nunew;
   double *Qqq, *Cqq, *Dg, *cs, *q0, *q1, *gfa, *grow, *Jq, *rc, *A5, *B5;
   double *Kg, *kff, *Pst;        // gains, cost-to-go (upper triangle of P, then p)
+  double *zeros;                 // [N][Bp] zero-filled, never written (source of structural zeros)
   double *part;                   // [P_COUNT][N][Bp]
   double *gphi;                   // [N][Bp]
   unsigned long long *amin_p, *amin_d;  // [Bp] fraction-to-the-boundary step lengths (bits of a positive double)
@@ -67,7 +68,8 @@ struct Ws {
   double *res_stat, *res_eq, *res_ineq, *res_comp, *obj;
   int *status, *iters, *ls, *cur, *newstep;
   int *redo, *force_gn, *gn_sticky, *curv_fail, *usedc, *stall;
-  int *active_hist;               // [max_passes]
+  int *active_hist;               // [max_passes] instances still iterating after each pass
+  int *act_idx, *n_act;           // compacted list of the instances still iterating, its length
 };
 
 #define IDX(slot, k, b) (((size_t)(slot) * W.N + (size_t)(k)) * W.Bp + (size_t)(b))
@@ -101,6 +103,8 @@ __global__ __launch_bounds__(256) void k_init(Ws W, const double *__restrict__ x
   if (b >= B) return;
   for (int j = 0; j < nx; j++) W.z[0][IDX(j, 0, b)] = xinit[(size_t)b * nx + j];
   W.status[b] = ST_ACTIVE;
+  W.act_idx[b] = b;
+  if (b == 0) *W.n_act = B;
   W.iters[b] = 0;
   W.ls[b] = 0;
   W.cur[b] = 0;
@@ -155,6 +159,38 @@ __global__ __launch_bounds__(256) void k_unpack(Ws W, double *__restrict__ zout,
 }
 
 // ===========================================================================
+// k_compact: ordered list of the instances that are still iterating.  All pass
+// kernels index their lanes through it, so wavefronts beyond the list exit at
+// once and the passes of the iteration tail touch a few wavefronts only.
+// ===========================================================================
+__global__ __launch_bounds__(1024) void k_compact(Ws W, int B, int pass) {
+  __shared__ int sums[1024];
+  const int tid = threadIdx.x;
+  const int per = (B + 1023) / 1024;
+  const int lo = tid * per, hi = (lo + per < B) ? lo + per : B;
+  int cnt = 0;
+  for (int b = lo; b < hi; b++) cnt += (W.status[b] == ST_ACTIVE);
+  sums[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (tid >= off) ? sums[tid - off] : 0;
+    __syncthreads();
+    sums[tid] += v;
+    __syncthreads();
+  }
+  const int total = sums[1023];
+  // while most instances are still iterating the identity list keeps every access coalesced
+  const bool dense = (total * 4 > B);
+  int base = dense ? lo : sums[tid] - cnt;
+  for (int b = lo; b < hi; b++)
+    if (dense || W.status[b] == ST_ACTIVE) W.act_idx[base++] = b;
+  if (tid == 1023) {
+    *W.n_act = dense ? B : total;
+    W.active_hist[pass] = total;
+  }
+}
+
+// ===========================================================================
 // k_sweep: stage-parallel function / Jacobian evaluation + condensing
 // ===========================================================================
 // Rows are processed in two groups so that every register array is indexed by an
@@ -170,9 +206,10 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const DevTables
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV;
   const DevTables &T = *Tp;
   const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int b = gid % W.Bp;
-  const int k = gid / W.Bp;  // uniform per wavefront (Bp % 64 == 0)
-  if (b >= B || k >= M.N) return;
+  const int li = gid % W.Bp;   // position in the compacted list of iterating instances
+  const int k = gid / W.Bp;    // uniform per wavefront (Bp % 64 == 0)
+  if (li >= *W.n_act || k >= M.N) return;
+  const int b = W.act_idx[li];
   if (W.status[b] != ST_ACTIVE) return;
   const int N = M.N;
   const int cur = W.cur[b], nxt = cur ^ 1;
@@ -576,28 +613,16 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const DevTables
 // ===========================================================================
 // k_riccati: per-instance decisions + block-tridiagonal Riccati recursion
 // ===========================================================================
-template <int NW>
-__device__ __forceinline__ bool chol_inplace(double (&Mx)[NW][NW]) {
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < NW; j++) {
-    double dg = Mx[j][j];
-#pragma unroll
-    for (int l = 0; l < j; l++) dg -= Mx[j][l] * Mx[j][l];
-    if (!(dg > 0.0)) ok = false;
-    dg = sqrt(dg);
-    Mx[j][j] = dg;
-    const double inv = 1.0 / dg;
-#pragma unroll
-    for (int i = j + 1; i < NW; i++) {
-      double s = Mx[i][j];
-#pragma unroll
-      for (int l = 0; l < j; l++) s -= Mx[i][l] * Mx[j][l];
-      Mx[i][j] = s * inv;
-    }
-  }
-  return ok;
-}
+// One 64-lane wavefront per instance.  The stage matrices live in LDS and every
+// small dense operation of the recursion is spread over the lanes (one output
+// entry per lane and pass), so the dependent chain per stage is a handful of
+// LDS round trips instead of ~1500 serial fp64 instructions of one lane.
+//   backward, stage k:  fill Q_k, q_k      (compact blocks -> dense (nx+nw)^2, lanes over entries)
+//                       T = P [A|B], Pc = P rc + p
+//                       Q += [A|B]^T T, q += [A|B]^T Pc
+//                       Cholesky of Qww (every lane, registers), gains K | kff (one column per lane)
+//                       P = sym(Qxx + Qxw K), p = qx + Qxw kff
+//   forward, stage k:   dw = K dx + kff, nu+ = P dx + p, dx+ = [A|B][dx; dw] + rc
 template <int NW>
 __device__ __forceinline__ void chol_solve(const double (&L)[NW][NW], double (&v)[NW]) {
 #pragma unroll
@@ -616,19 +641,49 @@ __device__ __forceinline__ void chol_solve(const double (&L)[NW][NW], double (&v
   }
 }
 
+// LDS hand-off inside ONE wavefront: DS instructions of a wave execute in issue order, so a
+// compiler-level ordering point is all that is needed (a __syncthreads() would also drain the
+// global loads that are deliberately left in flight as the next stage's prefetch).
+#define WSYNC()                                              \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
 template <class C>
 __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, const int B, const int first,
                                                 const int pass) {
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV, NW = C::NW;
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= B) return;
-  if (W.status[b] != ST_ACTIVE) return;
+  constexpr bool DD = (C::ROBOT == RMPC_ROBOT_DIFFDRIVE);
+  constexpr int NP2 = NX * (NX + 1) / 2;
+  const int li = blockIdx.x;
+  if (li >= *W.n_act) return;
+  const int b = W.act_idx[li];
+  if (W.status[b] != ST_ACTIVE) return;  // uniform: one instance per wavefront
+  const int lane = threadIdx.x;
   const int N = M.N;
-  W.newstep[b] = 0;
+  (void)B;
 
-  // ---- reduce the stage partials of the trial point (stage order) ---------------
-  double f = 0, th = 0, lgs = 0, rstat = 0, req = 0, rineq = 0, rcomp = 0, sumc = 0, minc = 1e300, badf = 0;
-  for (int k = 0; k < N; k++) {
+  // ---- reduce the stage partials of the trial point --------------------------------
+  double f = 0, th = 0, lgs = 0, rstat = 0, req = 0, rineq = 0, rcomp = 0, sumc = 0, minc = 1e300, badf = 0, gphi = 0;
+  for (int k = lane; k < N; k += 64) {
     f += W.part[IDX(P_F, k, b)];
     th += W.part[IDX(P_TH, k, b)];
     lgs += W.part[IDX(P_LOGS, k, b)];
@@ -639,20 +694,26 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
     sumc += W.part[IDX(P_SUMC, k, b)];
     minc = fmin(minc, W.part[IDX(P_MINC, k, b)]);
     badf += W.part[IDX(P_BAD, k, b)];
+    gphi += first ? 0.0 : W.gphi[(size_t)k * W.Bp + b];
   }
+  f = wave_sum(f); th = wave_sum(th); lgs = wave_sum(lgs); sumc = wave_sum(sumc); badf = wave_sum(badf);
+  gphi = wave_sum(gphi);
+  rstat = wave_max(rstat); req = wave_max(req); rineq = wave_max(rineq); rcomp = wave_max(rcomp);
+  minc = wave_min(minc);
+
+  // ---- decisions: every lane computes them (identical values), lane 0 stores ---------
+  const bool L0 = (lane == 0);
+  if (L0) W.newstep[b] = 0;
   double mu = W.mu[b];
   int status = ST_ACTIVE;
   int iters = W.iters[b];
   const bool redo = (!first) && (W.redo[b] != 0);
-
   if (first) {
     if (badf != 0.0) status = -7;  // inverse-barrier row not strictly feasible at the start
   } else if (redo) {
     // null pass: same point, the step is recomputed below with the Gauss-Newton blocks
-    W.redo[b] = 0;
+    if (L0) W.redo[b] = 0;
   } else {
-    double gphi = 0.0;
-    for (int k = 0; k < N; k++) gphi += W.gphi[(size_t)k * W.Bp + b];
     const double a0 = __longlong_as_double((long long)W.amin_p[b]);
     int ls = W.ls[b];
     double rho = W.rho[b], phi0 = W.phi0[b], Dd = W.Dd[b];
@@ -664,9 +725,7 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
       }
       Dd = gphi - rho * thc;
       phi0 = W.fcur[b] - mu * W.logcur[b] + rho * thc;
-      W.rho[b] = rho;
-      W.phi0[b] = phi0;
-      W.Dd[b] = Dd;
+      if (L0) { W.rho[b] = rho; W.phi0[b] = phi0; W.Dd[b] = Dd; }
     }
     const double alpha = ldexp(a0, -ls);
     const double phi = f - mu * lgs + rho * th;
@@ -678,36 +737,42 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
         if (usedc) {
           // the curvature step failed its line search: recompute this iteration's step with
           // the Gauss-Newton blocks (null pass next); latch after repeated failures
-          const int cf = W.curv_fail[b] + 1;
-          W.curv_fail[b] = cf;
-          if (cf >= kCurvFailMax) W.gn_sticky[b] = 1;
-          W.redo[b] = 1;
-          W.force_gn[b] = 1;
-          W.ls[b] = 0;
-          atomicAdd(&W.active_hist[pass], 1);
+          if (L0) {
+            const int cf = W.curv_fail[b] + 1;
+            W.curv_fail[b] = cf;
+            if (cf >= kCurvFailMax) W.gn_sticky[b] = 1;
+            W.redo[b] = 1;
+            W.force_gn[b] = 1;
+            W.ls[b] = 0;
+          }
           return;
         }
-        W.status[b] = -8;  // line search failure; the current iterate is returned
+        if (L0) W.status[b] = -8;  // line search failure; the current iterate is returned
         return;
       }
-      W.ls[b] = ls;
-      atomicAdd(&W.active_hist[pass], 1);
+      if (L0) W.ls[b] = ls;
       return;  // next sweep retries with alpha / 2
     }
-    if (usedc) W.curv_fail[b] = 0;
+    if (usedc && L0) W.curv_fail[b] = 0;
     iters++;
   }
   // ---- accept the trial point ------------------------------------------------------
   if (status == ST_ACTIVE) {
     const double f_prev = W.fcur[b];
-    W.cur[b] ^= 1;
-    W.ls[b] = 0;
-    W.fcur[b] = f;
-    W.thcur[b] = th;
-    W.logcur[b] = lgs;
+    const int stall0 = W.stall[b];
+    __builtin_amdgcn_s_waitcnt(0);  // every lane has read the per-instance words before lane 0 rewrites them
+    if (L0) {
+      W.cur[b] ^= 1;
+      W.ls[b] = 0;
+      W.fcur[b] = f;
+      W.thcur[b] = th;
+      W.logcur[b] = lgs;
+    }
     if (!redo) {
-      W.iters[b] = iters;
-      W.res_stat[b] = rstat; W.res_eq[b] = req; W.res_ineq[b] = rineq; W.res_comp[b] = rcomp; W.obj[b] = f;
+      if (L0) {
+        W.iters[b] = iters;
+        W.res_stat[b] = rstat; W.res_eq[b] = req; W.res_ineq[b] = rineq; W.res_comp[b] = rcomp; W.obj[b] = f;
+      }
       if (!first) {
         // LOQO-style centrality rule with floors (DESIGN.md, section "Algorithm")
         const double cnt = (double)N * (double)M.m;
@@ -720,7 +785,7 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
         if (sg > 0.8) sg = 0.8;
         mu = sg * avg;
         if (mu < 0.1 * M.tol_comp) mu = 0.1 * M.tol_comp;
-        W.mu[b] = mu;
+        if (L0) W.mu[b] = mu;
         if (!(mu < kMuDiverged)) status = -7;
       }
       if (status == ST_ACTIVE) {
@@ -728,13 +793,13 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
         else if (rstat <= M.tol_stat && req <= M.tol_eq && rineq <= M.tol_ineq && rcomp <= M.tol_comp) status = 1;
         else {
           // acceptable termination: feasible, complementary, objective stagnant for acc_iters iterations
-          int stall = W.stall[b];
+          int stall = stall0;
           if (!first && req <= kAccFeas && rineq <= kAccFeas && rcomp <= kAccFeas &&
               fabs(f - f_prev) <= M.acc_obj_tol * fmax(1.0, fabs(f)))
             stall++;
           else
             stall = 0;
-          W.stall[b] = stall;
+          if (L0) W.stall[b] = stall;
           if (M.acc_iters > 0 && stall >= M.acc_iters) status = 2;
           else if (iters >= M.max_iter) status = 0;
         }
@@ -742,215 +807,173 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
     }
   }
   if (status != ST_ACTIVE) {
-    W.status[b] = status;
+    if (L0) W.status[b] = status;
     return;
   }
   // exact constraint curvature unless latched off or this is the fallback pass
   bool usec = false;
   if constexpr (C::CURV) usec = M.use_curv && !W.gn_sticky[b] && !W.force_gn[b] && (mu <= kCurvMu);
-  W.force_gn[b] = 0;
+  __builtin_amdgcn_s_waitcnt(0);
+  if (L0) W.force_gn[b] = 0;
   const double cwt = usec ? 1.0 : 0.0;  // Cqq is zero-filled when the model does not use it
 
-  // ---- Riccati recursion ---------------------------------------------------------------
-  // Explicit load phases: the inputs of stage k-1 are requested before stage k is computed
-  // (register double buffer), so one HBM/L2 round trip per stage is off the dependent chain.
-  // P and Qxx are kept as upper triangles.
-  constexpr bool DD = (C::ROBOT == RMPC_ROBOT_DIFFDRIVE);
-  constexpr int NQ2 = C::NQ2, NDG = NV - NQ, NP2 = NX * (NX + 1) / 2;
-  struct StageIn {
-    double qq[NQ2], dg[NDG], cs[NS > 0 ? NV : 1], q[NV], rc[NX];
-    double A5[DD ? 25 : 1], B5[DD ? 10 : 1];
+  // ---- LDS images -------------------------------------------------------------------------
+  __shared__ double sP[NX * NX], sp[NX], sAB[NX * NV], sQ[NV * NV], sq[NV], sT[NX * NV], sPc[NX], src[NX];
+  __shared__ double sK[NW * NX], skf[NW], sdx[NX], sdw[NW];
+  const double h = M.dt, h2 = 0.5 * M.dt * M.dt;
+
+  // [A | B] of the holonomic chain is constant: A = [I hI; 0 I], B = [h2 I; h I] on the u columns
+  auto fill_AB_chain = [&]() __attribute__((always_inline)) {
+    for (int e = lane; e < NX * NV; e += 64) {
+      const int i = e / NV, j = e - i * NV;
+      double v = 0.0;
+      if (j < NX) {
+        if (i == j) v = 1.0;
+        else if (i < NQ && j == i + NQ) v = h;
+      } else if (j >= NX + NS) {
+        const int c = j - NX - NS;
+        if (i < NQ && c == i) v = h2;
+        else if (i >= NQ && c == i - NQ) v = h;
+      }
+      sAB[e] = v;
+    }
   };
-  auto load_stage = [&](int k, StageIn &s) __attribute__((always_inline)) {
+  // Loop-invariant source of every LDS entry this lane fills: a pointer into the workspace
+  // (stage 0 of the right slot, or a zero-filled array) plus a constant.  The per-stage fetch is
+  // then an unconditional load per entry -- no branch around any load.
+  const double *const zer = W.zeros + b;
+  const size_t sstr = (size_t)W.Bp;  // stage stride
+  constexpr int EPL = (NV * NV + 63) / 64;   // stage Hessian entries per lane
+  constexpr int TPL = (NX * NV + 63) / 64;   // entries of T = P [A|B] (and of [A|B]) per lane
+  constexpr int PPL = (NX * NX + 63) / 64;   // entries of P per lane
+  const double *qp[EPL], *cp[EPL];
 #pragma unroll
-    for (int i = 0; i < NQ2; i++) {
-      double v = W.Qqq[IDX(i, k, b)];
-      if constexpr (C::CURV) v -= cwt * W.Cqq[IDX(i, k, b)];  // unconditional load, 0/1 weight
-      s.qq[i] = v;
+  for (int u = 0; u < EPL; u++) {
+    const int e = lane + 64 * u;
+    qp[u] = zer; cp[u] = zer;
+    if (e < NV * NV) {
+      const int i = e / NV, j = e - i * NV;
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      if (hi < NQ) {
+        const int s = lo * NQ - lo * (lo - 1) / 2 + (hi - lo);
+        qp[u] = W.Qqq + IDX(s, 0, b);
+        if constexpr (C::CURV) cp[u] = W.Cqq + IDX(s, 0, b);
+      } else if (lo == hi) {
+        qp[u] = W.Dg + IDX(lo - NQ, 0, b);
+      } else if (NS > 0 && lo == NX) {
+        qp[u] = W.cs + IDX(hi, 0, b);
+      } else if (NS > 0 && hi == NX) {
+        qp[u] = W.cs + IDX(lo, 0, b);
+      }
     }
+  }
+  const double *q0p = lane < NV ? W.q0 + IDX(lane, 0, b) : zer;
+  const double *q1p = lane < NV ? W.q1 + IDX(lane, 0, b) : zer;
+  const double *rcp = lane < NX ? W.rc + IDX(lane, 0, b) : zer;
+  // [A|B] of the diff-drive model: identity outside the reduced (x, y, theta, v, omega) block
+  const double *abp[DD ? TPL : 1];
+  double abc[DD ? TPL : 1];
+  if constexpr (DD) {
 #pragma unroll
-    for (int i = 0; i < NDG; i++) s.dg[i] = W.Dg[IDX(i, k, b)];
-    if constexpr (NS > 0) {
-#pragma unroll
-      for (int i = 0; i < NV; i++) s.cs[i] = W.cs[IDX(i, k, b)];
+    for (int u = 0; u < TPL; u++) {
+      const int e = lane + 64 * u;
+      abp[u] = zer; abc[u] = 0.0;
+      if (e < NX * NV) {
+        const int i = e / NV, j = e - i * NV;
+        const int ri = (i < 3) ? i : (i >= 6 ? i - 3 : -1);
+        if (j < NX) {
+          const int rj = (j < 3) ? j : (j >= 6 ? j - 3 : -1);
+          if (ri >= 0 && rj >= 0) abp[u] = W.A5 + IDX(ri * 5 + rj, 0, b);
+          else abc[u] = (i == j) ? 1.0 : 0.0;
+        } else if (j >= NX + NS && ri >= 0) {
+          abp[u] = W.B5 + IDX(ri * 2 + (j - NX - NS), 0, b);
+        }
+      }
     }
-#pragma unroll
-    for (int i = 0; i < NV; i++) s.q[i] = W.q0[IDX(i, k, b)] - mu * W.q1[IDX(i, k, b)];
-    // the last stage has no successor: these reads are in bounds, finite (zero-filled at create)
-    // and never used
-#pragma unroll
-    for (int i = 0; i < NX; i++) s.rc[i] = W.rc[IDX(i, k, b)];
+  }
+  auto fill_AB_dd = [&](int k) __attribute__((always_inline)) {
     if constexpr (DD) {
 #pragma unroll
-      for (int i = 0; i < 25; i++) s.A5[i] = W.A5[IDX(i, k, b)];
-#pragma unroll
-      for (int i = 0; i < 10; i++) s.B5[i] = W.B5[IDX(i, k, b)];
+      for (int u = 0; u < TPL; u++) {
+        const int e = lane + 64 * u;
+        const double v = abp[u][(size_t)k * sstr] + abc[u];
+        if (e < NX * NV) sAB[e] = v;
+      }
     }
   };
-  // upper-triangle accessors (indices are compile-time constants after unrolling)
-#define UP(Mx, i, j) ((i) <= (j) ? Mx[i][j] : Mx[j][i])
 
-  double Pm[NX][NX], pv[NX];
+  if constexpr (!DD) fill_AB_chain();
+  for (int e = lane; e < NX * NX; e += 64) sP[e] = 0.0;
+  if (lane < NX) sp[lane] = 0.0;
   bool chol_ok = true;
-  const double h = M.dt, h2 = 0.5 * M.dt * M.dt;
-#pragma unroll
-  for (int i = 0; i < NX; i++) {
-    pv[i] = 0;
-#pragma unroll
-    for (int j = 0; j < NX; j++) Pm[i][j] = 0;
-  }
-  constexpr bool PREFETCH = (NX <= 8);  // the 14-state arm has no registers to spare for a second buffer
-  StageIn cur, nxt;
-  if constexpr (PREFETCH) load_stage(N - 1, cur);
-  for (int k = N - 1; k >= 0; k--) {
-    if constexpr (PREFETCH) load_stage(k > 0 ? k - 1 : 0, nxt);
-    else load_stage(k, cur);
-    asm volatile("" ::: "memory");  // keep the loads above the computation of stage k
-    double Qxx[NX][NX], Qxw[NX][NW], Qww[NW][NW], qx[NX], qw[NW];
-#pragma unroll
-    for (int i = 0; i < NX; i++) {
-#pragma unroll
-      for (int j = 0; j < NX; j++) Qxx[i][j] = 0;
-#pragma unroll
-      for (int j = 0; j < NW; j++) Qxw[i][j] = 0;
-    }
-#pragma unroll
-    for (int i = 0; i < NW; i++)
-#pragma unroll
-      for (int j = 0; j < NW; j++) Qww[i][j] = 0;
-    {
-      int s = 0;
-#pragma unroll
-      for (int a = 0; a < NQ; a++)
-#pragma unroll
-        for (int c = a; c < NQ; c++) Qxx[a][c] = cur.qq[s++];
-    }
-#pragma unroll
-    for (int j = NQ; j < NX; j++) Qxx[j][j] = cur.dg[j - NQ];
-#pragma unroll
-    for (int j = 0; j < NW; j++) Qww[j][j] = cur.dg[NX + j - NQ];
-    if constexpr (NS > 0) {
-#pragma unroll
-      for (int j = 0; j < NX; j++) Qxw[j][0] = cur.cs[j];
-#pragma unroll
-      for (int j = 0; j < NU; j++) Qww[0][1 + j] = cur.cs[NX + 1 + j];
-    }
-#pragma unroll
-    for (int j = 0; j < NX; j++) qx[j] = cur.q[j];
-#pragma unroll
-    for (int j = 0; j < NW; j++) qw[j] = cur.q[NX + j];
 
-    if (k < N - 1) {
-      double Pc[NX];
+  // prefetched inputs of the stage about to be processed
+  double qv[EPL], qlin = 0.0, rcv = 0.0;
+  auto fetch_stage = [&](int k) __attribute__((always_inline)) {
+    const size_t o = (size_t)k * sstr;
 #pragma unroll
-      for (int i = 0; i < NX; i++) {
-        double s = pv[i];
+    for (int u = 0; u < EPL; u++) qv[u] = qp[u][o] - cwt * cp[u][o];
+    qlin = q0p[o] - mu * q1p[o];
+    rcv = rcp[o];   // stage N-1: finite, unused
+  };
+  fetch_stage(N - 1);
+  for (int k = N - 1; k >= 0; k--) {
+    // -- fill ------------------------------------------------------------------------------
 #pragma unroll
-        for (int l = 0; l < NX; l++) s += UP(Pm, i, l) * cur.rc[l];
-        Pc[i] = s;
-      }
-      if constexpr (!DD) {
-        // A = [I hI; 0 I], B = [h2 I; h I] (u columns): O(n^2) block algebra
-#pragma unroll
-        for (int i = 0; i < NQ; i++) {
-#pragma unroll
-          for (int j = 0; j < NQ; j++) {
-            const double p11 = UP(Pm, i, j), p12 = UP(Pm, i, NQ + j), p21 = UP(Pm, NQ + i, j), p22 = UP(Pm, NQ + i, NQ + j);
-            const double pa12 = h * p11 + p12;
-            const double pa22 = h * p21 + p22;
-            const double pb1 = h2 * p11 + h * p12;
-            const double pb2 = h2 * p21 + h * p22;
-            if (i <= j) {
-              Qxx[i][j] += p11;
-              Qxx[NQ + i][NQ + j] += h * pa12 + pa22;
-              Qww[NS + i][NS + j] += h2 * pb1 + h * pb2;
-            }
-            Qxx[i][NQ + j] += pa12;
-            Qxw[i][NS + j] += pb1;
-            Qxw[NQ + i][NS + j] += h * pb1 + pb2;
-          }
-          qx[i] += Pc[i];
-          qx[NQ + i] += h * Pc[i] + Pc[NQ + i];
-          qw[NS + i] += h2 * Pc[i] + h * Pc[NQ + i];
-        }
-      } else {
-        // dense A (8x8) rebuilt from the reduced 5x5 block, B (8x2)
-        constexpr int map[5] = {0, 1, 2, 6, 7};
-        double A[NX][NX], Bm[NX][NU];
-#pragma unroll
-        for (int i = 0; i < NX; i++) {
-#pragma unroll
-          for (int j = 0; j < NX; j++) A[i][j] = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-          for (int j = 0; j < NU; j++) Bm[i][j] = 0.0;
-        }
-#pragma unroll
-        for (int r = 0; r < 5; r++) {
-#pragma unroll
-          for (int c = 0; c < 5; c++) A[map[r]][map[c]] = cur.A5[r * 5 + c];
-#pragma unroll
-          for (int c = 0; c < 2; c++) Bm[map[r]][c] = cur.B5[r * 2 + c];
-        }
-        double PA[NX][NX], PB[NX][NU];
-#pragma unroll
-        for (int i = 0; i < NX; i++) {
-#pragma unroll
-          for (int j = 0; j < NX; j++) {
-            double s = 0;
-#pragma unroll
-            for (int l = 0; l < NX; l++) s += UP(Pm, i, l) * A[l][j];
-            PA[i][j] = s;
-          }
-#pragma unroll
-          for (int j = 0; j < NU; j++) {
-            double s = 0;
-#pragma unroll
-            for (int l = 0; l < NX; l++) s += UP(Pm, i, l) * Bm[l][j];
-            PB[i][j] = s;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < NX; i++) {
-#pragma unroll
-          for (int j = i; j < NX; j++) {
-            double s = 0;
-#pragma unroll
-            for (int l = 0; l < NX; l++) s += A[l][i] * PA[l][j];
-            Qxx[i][j] += s;
-          }
-#pragma unroll
-          for (int j = 0; j < NU; j++) {
-            double s = 0;
-#pragma unroll
-            for (int l = 0; l < NX; l++) s += A[l][i] * PB[l][j];
-            Qxw[i][NS + j] += s;
-          }
-          double s = 0;
-#pragma unroll
-          for (int l = 0; l < NX; l++) s += A[l][i] * Pc[l];
-          qx[i] += s;
-        }
-#pragma unroll
-        for (int i = 0; i < NU; i++) {
-#pragma unroll
-          for (int j = i; j < NU; j++) {
-            double s = 0;
-#pragma unroll
-            for (int l = 0; l < NX; l++) s += Bm[l][i] * PB[l][j];
-            Qww[NS + i][NS + j] += s;
-          }
-          double s = 0;
-#pragma unroll
-          for (int l = 0; l < NX; l++) s += Bm[l][i] * Pc[l];
-          qw[NS + i] += s;
-        }
-      }
+    for (int u = 0; u < EPL; u++) {
+      const int e = lane + 64 * u;
+      if (e < NV * NV) sQ[e] = qv[u];
     }
-    // Cholesky of Qww (upper triangle in, lower factor out)
+    if (lane < NV) sq[lane] = qlin;
+    if (lane < NX) src[lane] = rcv;
+    if (k < N - 1) fill_AB_dd(k);
+    if (k > 0) fetch_stage(k - 1);  // requests for the next stage travel while this one is computed
+    WSYNC();
+    if (k < N - 1) {
+      // -- T = P [A|B], Pc = P rc + p ---------------------------------------------------------
+#pragma unroll
+      for (int u = 0; u < TPL; u++) {
+        const int e = lane + 64 * u;
+        if (e < NX * NV) {
+          const int i = e / NV, j = e - i * NV;
+          double s = 0.0;
+#pragma unroll
+          for (int l = 0; l < NX; l++) s += sP[i * NX + l] * sAB[l * NV + j];
+          sT[e] = s;
+        }
+      }
+      if (lane < NX) {
+        double s = sp[lane];
+#pragma unroll
+        for (int l = 0; l < NX; l++) s += sP[lane * NX + l] * src[l];
+        sPc[lane] = s;
+      }
+      WSYNC();
+      // -- Q += [A|B]^T T, q += [A|B]^T Pc ---------------------------------------------------------
+#pragma unroll
+      for (int u = 0; u < EPL; u++) {
+        const int e = lane + 64 * u;
+        if (e < NV * NV) {
+          const int i = e / NV, j = e - i * NV;
+          double s = sQ[e];
+#pragma unroll
+          for (int l = 0; l < NX; l++) s += sAB[l * NV + i] * sT[l * NV + j];
+          sQ[e] = s;
+        }
+      }
+      if (lane < NV) {
+        double s = sq[lane];
+#pragma unroll
+        for (int l = 0; l < NX; l++) s += sAB[l * NV + lane] * sPc[l];
+        sq[lane] = s;
+      }
+      WSYNC();
+    }
+    // -- Cholesky of Qww: every lane factors the small block in registers --------------------------
     double L[NW][NW];
 #pragma unroll
     for (int j = 0; j < NW; j++) {
-      double dg = Qww[j][j];
+      double dg = sQ[(NX + j) * NV + NX + j];
 #pragma unroll
       for (int l = 0; l < j; l++) dg -= L[j][l] * L[j][l];
       if (!(dg > 0.0)) chol_ok = false;
@@ -959,164 +982,150 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
       const double inv = 1.0 / dg;
 #pragma unroll
       for (int i = j + 1; i < NW; i++) {
-        double s = Qww[j][i];
+        double s = sQ[(NX + i) * NV + NX + j];
 #pragma unroll
         for (int l = 0; l < j; l++) s -= L[i][l] * L[j][l];
         L[i][j] = s * inv;
       }
     }
-    double Kx[NW][NX], kf[NW];
-#pragma unroll
-    for (int j = 0; j < NX; j++) {
+    // -- gains: lane c < NX solves for column c of K, lane NX for kff -----------------------------------
+    if (lane <= NX) {
       double col[NW];
 #pragma unroll
-      for (int i = 0; i < NW; i++) col[i] = -Qxw[j][i];
+      for (int i = 0; i < NW; i++) col[i] = (lane < NX) ? -sQ[(NX + i) * NV + lane] : -sq[NX + i];
       chol_solve<NW>(L, col);
+      if (lane < NX) {
 #pragma unroll
-      for (int i = 0; i < NW; i++) Kx[i][j] = col[i];
-    }
+        for (int i = 0; i < NW; i++) { sK[i * NX + lane] = col[i]; W.Kg[IDX(i * NX + lane, k, b)] = col[i]; }
+      } else {
 #pragma unroll
-    for (int i = 0; i < NW; i++) kf[i] = -qw[i];
-    chol_solve<NW>(L, kf);
-    // cost-to-go (upper triangle)
-#pragma unroll
-    for (int i = 0; i < NX; i++) {
-#pragma unroll
-      for (int j = i; j < NX; j++) {
-        double s = Qxx[i][j];
-#pragma unroll
-        for (int l = 0; l < NW; l++) s += Qxw[i][l] * Kx[l][j];
-        Pm[i][j] = s;
+        for (int i = 0; i < NW; i++) { skf[i] = col[i]; W.kff[IDX(i, k, b)] = col[i]; }
       }
-      double s = qx[i];
-#pragma unroll
-      for (int l = 0; l < NW; l++) s += Qxw[i][l] * kf[l];
-      pv[i] = s;
     }
+    WSYNC();
+    // -- cost-to-go: P = sym(Qxx + Qxw K), p = qx + Qxw kff ---------------------------------------------
+    double pn[PPL], pnv = 0.0;
 #pragma unroll
-    for (int i = 0; i < NW; i++) {
-      W.kff[IDX(i, k, b)] = kf[i];
+    for (int u = 0; u < PPL; u++) {
+      const int e = lane + 64 * u;
+      pn[u] = 0.0;
+      if (e < NX * NX) {
+        const int i = e / NX, j = e - i * NX;
+        double a = sQ[i * NV + j], c = sQ[j * NV + i];
 #pragma unroll
-      for (int j = 0; j < NX; j++) W.Kg[IDX(i * NX + j, k, b)] = Kx[i][j];
+        for (int l = 0; l < NW; l++) {
+          a += sQ[i * NV + NX + l] * sK[l * NX + j];
+          c += sQ[j * NV + NX + l] * sK[l * NX + i];
+        }
+        pn[u] = 0.5 * (a + c);
+      }
     }
-    {
-      int s = 0;
+    if (lane < NX) {
+      double s = sq[lane];
 #pragma unroll
-      for (int i = 0; i < NX; i++)
-#pragma unroll
-        for (int j = i; j < NX; j++) W.Pst[IDX(s++, k, b)] = Pm[i][j];
-#pragma unroll
-      for (int i = 0; i < NX; i++) W.Pst[IDX(NP2 + i, k, b)] = pv[i];
+      for (int l = 0; l < NW; l++) s += sQ[lane * NV + NX + l] * skf[l];
+      pnv = s;
     }
-    if constexpr (PREFETCH) cur = nxt;
+    WSYNC();
+#pragma unroll
+    for (int u = 0; u < PPL; u++) {
+      const int e = lane + 64 * u;
+      if (e < NX * NX) {
+        sP[e] = pn[u];
+        const int i = e / NX, j = e - i * NX;
+        if (i <= j) W.Pst[IDX(i * NX - i * (i - 1) / 2 + (j - i), k, b)] = pn[u];
+      }
+    }
+    if (lane < NX) { sp[lane] = pnv; W.Pst[IDX(NP2 + lane, k, b)] = pnv; }
+    // (the fill of the next stage touches sQ / sq / src only; its barrier orders the sP writes)
   }
   if (!chol_ok) {
     if (usec) {
       // reduced Hessian not positive definite with the curvature terms: recompute this
       // iteration's step with the Gauss-Newton blocks (null pass next); not counted as a
       // line-search failure
-      W.redo[b] = 1;
-      W.force_gn[b] = 1;
-      W.usedc[b] = 0;
-      atomicAdd(&W.active_hist[pass], 1);
+      if (L0) { W.redo[b] = 1; W.force_gn[b] = 1; W.usedc[b] = 0; }
       return;
     }
-    W.status[b] = -5;
+    if (L0) W.status[b] = -5;
     return;
   }
-  W.usedc[b] = usec ? 1 : 0;
+  if (L0) W.usedc[b] = usec ? 1 : 0;
 
-  // ---- forward rollout + costates nu+_k = P_k dx_k + p_k ------------------------------------
-  struct FwdIn {
-    double Kx[NW * NX], kf[NW], Pu[NP2], pp[NX], rc[NX];
-    double A5[DD ? 25 : 1], B5[DD ? 10 : 1];
+  // ---- forward rollout + costates nu+_k = P_k dx_k + p_k ------------------------------------------
+  // gains and cost-to-go of stage 0 are still in LDS; later stages are re-read (one element per lane)
+  WSYNC();
+  if (lane < NX) sdx[lane] = 0.0;
+  constexpr int FPL = (NW * NX + NW + NX * NX + NX + NX + 63) / 64;
+  double fv[FPL];
+  const double *fp[FPL];
+#pragma unroll
+  for (int u = 0; u < FPL; u++) {
+    int e = lane + 64 * u;
+    fp[u] = zer;
+    if (e < NW * NX) fp[u] = W.Kg + IDX(e, 0, b);
+    else if ((e -= NW * NX) < NW) fp[u] = W.kff + IDX(e, 0, b);
+    else if ((e -= NW) < NX * NX) {
+      const int i = e / NX, j = e - i * NX;
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      fp[u] = W.Pst + IDX(lo * NX - lo * (lo - 1) / 2 + (hi - lo), 0, b);
+    } else if ((e -= NX * NX) < NX) fp[u] = W.Pst + IDX(NP2 + e, 0, b);
+    else if ((e -= NX) < NX) fp[u] = W.rc + IDX(e, 0, b);
+  }
+  auto fetch_fwd = [&](int k) __attribute__((always_inline)) {
+    const size_t o = (size_t)k * sstr;
+#pragma unroll
+    for (int u = 0; u < FPL; u++) fv[u] = fp[u][o];
   };
-  auto load_fwd = [&](int k, FwdIn &s) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NW * NX; i++) s.Kx[i] = W.Kg[IDX(i, k, b)];
-#pragma unroll
-    for (int i = 0; i < NW; i++) s.kf[i] = W.kff[IDX(i, k, b)];
-#pragma unroll
-    for (int i = 0; i < NP2; i++) s.Pu[i] = W.Pst[IDX(i, k, b)];
-#pragma unroll
-    for (int i = 0; i < NX; i++) s.pp[i] = W.Pst[IDX(NP2 + i, k, b)];
-#pragma unroll
-    for (int i = 0; i < NX; i++) s.rc[i] = W.rc[IDX(i, k, b)];
-    if constexpr (DD) {
-#pragma unroll
-      for (int i = 0; i < 25; i++) s.A5[i] = W.A5[IDX(i, k, b)];
-#pragma unroll
-      for (int i = 0; i < 10; i++) s.B5[i] = W.B5[IDX(i, k, b)];
-    }
-  };
-  double dx[NX];
-#pragma unroll
-  for (int j = 0; j < NX; j++) dx[j] = 0.0;
-  FwdIn fc, fn;
-  if constexpr (PREFETCH) load_fwd(0, fc);
+  fetch_fwd(0);
   for (int k = 0; k < N; k++) {
-    if constexpr (PREFETCH) load_fwd(k < N - 1 ? k + 1 : k, fn);
-    else load_fwd(k, fc);
-    asm volatile("" ::: "memory");
-    double dw[NW];
 #pragma unroll
-    for (int i = 0; i < NW; i++) {
-      double s = fc.kf[i];
-#pragma unroll
-      for (int j = 0; j < NX; j++) s += fc.Kx[i * NX + j] * dx[j];
-      dw[i] = s;
+    for (int u = 0; u < FPL; u++) {
+      int e = lane + 64 * u;
+      if (e < NW * NX) sK[e] = fv[u];
+      else if ((e -= NW * NX) < NW) skf[e] = fv[u];
+      else if ((e -= NW) < NX * NX) sP[e] = fv[u];
+      else if ((e -= NX * NX) < NX) sp[e] = fv[u];
+      else if ((e -= NX) < NX) src[e] = fv[u];
     }
+    if (k < N - 1) fill_AB_dd(k);
+    if (k < N - 1) fetch_fwd(k + 1);
+    WSYNC();
+    if (lane < NW) {
+      double s = skf[lane];
 #pragma unroll
-    for (int j = 0; j < NX; j++) W.dz[IDX(j, k, b)] = dx[j];
+      for (int j = 0; j < NX; j++) s += sK[lane * NX + j] * sdx[j];
+      sdw[lane] = s;
+      W.dz[IDX(NX + lane, k, b)] = s;
+    } else if (lane < NW + NX) {
+      const int i = lane - NW;
+      W.dz[IDX(i, k, b)] = sdx[i];
+      if (k >= 1) {
+        double s = sp[i];
 #pragma unroll
-    for (int i = 0; i < NW; i++) W.dz[IDX(NX + i, k, b)] = dw[i];
-    if (k >= 1) {
-      // upper-triangle P_k: element (i, j), i <= j, at i*NX - i(i-1)/2 + (j - i)
-#pragma unroll
-      for (int i = 0; i < NX; i++) {
-        double s = fc.pp[i];
-#pragma unroll
-        for (int j = 0; j < NX; j++) {
-          const int lo = i < j ? i : j, hi = i < j ? j : i;
-          s += fc.Pu[lo * NX - lo * (lo - 1) / 2 + (hi - lo)] * dx[j];
-        }
+        for (int j = 0; j < NX; j++) s += sP[i * NX + j] * sdx[j];
         W.nunew[IDX(i, k, b)] = s;
       }
     }
-    if (k < N - 1) {
-      double dxn[NX];
-      if constexpr (!DD) {
+    WSYNC();
+    double dxn = 0.0;
+    if (k < N - 1 && lane < NX) {
+      double s = src[lane];
 #pragma unroll
-        for (int i = 0; i < NQ; i++) {
-          dxn[i] = fc.rc[i] + dx[i] + h * dx[NQ + i] + h2 * dw[NS + i];
-          dxn[NQ + i] = fc.rc[NQ + i] + dx[NQ + i] + h * dw[NS + i];
-        }
-      } else {
-        constexpr int map[5] = {0, 1, 2, 6, 7};
+      for (int j = 0; j < NX; j++) s += sAB[lane * NV + j] * sdx[j];
 #pragma unroll
-        for (int j = 0; j < NX; j++) dxn[j] = fc.rc[j];
-#pragma unroll
-        for (int j = 3; j < 6; j++) dxn[j] += dx[j];
-#pragma unroll
-        for (int r = 0; r < 5; r++) {
-          double s = 0;
-#pragma unroll
-          for (int c = 0; c < 5; c++) s += fc.A5[r * 5 + c] * dx[map[c]];
-#pragma unroll
-          for (int c = 0; c < 2; c++) s += fc.B5[r * 2 + c] * dw[NS + c];
-          dxn[map[r]] += s;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < NX; j++) dx[j] = dxn[j];
+      for (int j = 0; j < NW; j++) s += sAB[lane * NV + NX + j] * sdw[j];
+      dxn = s;
     }
-    if constexpr (PREFETCH) fc = fn;
+    WSYNC();
+    if (k < N - 1 && lane < NX) sdx[lane] = dxn;
+    // (next iteration's barrier orders this write before the reads)
   }
-#undef UP
-  W.newstep[b] = 1;
-  W.amin_p[b] = (unsigned long long)__double_as_longlong(1.0);  // k_step takes the minima next
-  W.amin_d[b] = (unsigned long long)__double_as_longlong(1.0);
-  atomicAdd(&W.active_hist[pass], 1);
+  if (L0) {
+    W.newstep[b] = 1;
+    W.amin_p[b] = (unsigned long long)__double_as_longlong(1.0);  // k_step takes the minima next
+    W.amin_d[b] = (unsigned long long)__double_as_longlong(1.0);
+  }
 }
 
 // ===========================================================================
@@ -1128,9 +1137,10 @@ __global__ __launch_bounds__(256) void k_step(const DevModel M, const DevTables 
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NV = C::NV;
   const DevTables &T = *Tp;
   const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int b = gid % W.Bp;
+  const int li = gid % W.Bp;
   const int k = gid / W.Bp;
-  if (b >= B || k >= M.N) return;
+  if (li >= *W.n_act || k >= M.N) return;
+  const int b = W.act_idx[li];
   if (W.status[b] != ST_ACTIVE || !W.newstep[b]) return;
   const int cur = W.cur[b];
   const double *__restrict__ zc = W.z[cur];
@@ -1289,8 +1299,8 @@ static int build_tables(const rmpc_desc &d, const DevModel &M, DevTables &T, std
     T.slot_row_begin[s] = r;
     for (const FkRow &fr : rows)
       if (fr.slot == s) {
-        T.fk_row[r] = (int16_t)fr.row; T.fk_kind[r] = (int8_t)fr.kind; T.fk_obst[r] = (int8_t)fr.obst;
-        T.fk_mod[r] = (int8_t)fr.mod; T.fk_first[r] = (int8_t)fr.first; T.fk_idx[r] = (int16_t)fr.idx;
+        T.fk_row[r] = fr.row; T.fk_kind[r] = fr.kind; T.fk_obst[r] = fr.obst;
+        T.fk_mod[r] = fr.mod; T.fk_first[r] = fr.first; T.fk_idx[r] = fr.idx;
         r++;
       }
   }
@@ -1300,9 +1310,9 @@ static int build_tables(const rmpc_desc &d, const DevModel &M, DevTables &T, std
   auto add_var_row = [&](int var, int row, int sgn, int poff, double val, int soft, int mod, int firstrow) -> bool {
     for (int u = 0; u < kVarRows; u++)
       if (T.v_row[var][u] < 0) {
-        T.v_row[var][u] = (int16_t)row; T.v_sgn[var][u] = (int8_t)sgn; T.v_poff[var][u] = (int16_t)poff;
-        T.v_val[var][u] = val; T.v_soft[var][u] = (int8_t)soft; T.v_mod[var][u] = (int8_t)mod;
-        T.v_first[var][u] = (int8_t)firstrow;
+        T.v_row[var][u] = row; T.v_sgn[var][u] = sgn; T.v_poff[var][u] = poff;
+        T.v_val[var][u] = val; T.v_soft[var][u] = soft; T.v_mod[var][u] = mod;
+        T.v_first[var][u] = firstrow;
         return true;
       }
     return false;
@@ -1385,7 +1395,7 @@ static int build_model(const rmpc_desc &d, DevModel &M, std::string &err) {
     auto push = [&](int kind, int a, int bb, int poff, bool fk) -> bool {
       if (row >= kMaxRows) return false;
       M.row_kind[row] = (int8_t)kind; M.row_a[row] = (int8_t)a; M.row_b[row] = (int8_t)bb;
-      M.row_poff[row] = (int16_t)poff; M.row_fk[row] = fk ? (int8_t)nfk++ : (int8_t)-1; M.row_mod[row] = (int8_t)mi;
+      M.row_poff[row] = poff; M.row_fk[row] = fk ? (int8_t)nfk++ : (int8_t)-1; M.row_mod[row] = (int8_t)mi;
       row++;
       return true;
     };
@@ -1518,6 +1528,7 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   W.Kg = c.take<double>(S * M.nw * M.nx);
   W.kff = c.take<double>(S * M.nw);
   W.Pst = c.take<double>(S * (M.nx * (M.nx + 1) / 2 + M.nx));
+  W.zeros = c.take<double>(S);
   W.part = c.take<double>(S * P_COUNT);
   W.gphi = c.take<double>(S);
   W.amin_p = c.take<unsigned long long>(Bp);
@@ -1528,6 +1539,8 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   int **peri[] = {&W.status, &W.iters, &W.ls, &W.cur, &W.newstep, &W.redo, &W.force_gn, &W.gn_sticky, &W.curv_fail, &W.usedc, &W.stall};
   for (auto pp : peri) *pp = c.take<int>(Bp);
   W.active_hist = c.take<int>(max_passes + 8);
+  W.act_idx = c.take<int>(Bp);
+  W.n_act = c.take<int>(64);
   return (c.off + 255) & ~(size_t)255;
 }
 
@@ -1561,7 +1574,7 @@ template <class C>
 static void launch_pass(rmpc_handle *h, int B, int first, int pass, hipStream_t st, int which) {
   const int lanes = h->Bp * h->M.N;
   if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, h->W, B, first);
-  else if (which == K_RICCATI) hipLaunchKernelGGL((k_riccati<C>), dim3((B + 63) / 64), dim3(64), 0, st, h->M, h->W, B, first, pass);
+  else if (which == K_RICCATI) hipLaunchKernelGGL((k_riccati<C>), dim3(B), dim3(64), 0, st, h->M, h->W, B, first, pass);
   else hipLaunchKernelGGL((k_step<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, h->W, B);
 }
 
@@ -1633,6 +1646,7 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
     const int first = pass == 0;
     { ProfScope ps(h, st, K_SWEEP); launch_variant(h, B, first, pass, st, K_SWEEP); }
     { ProfScope ps(h, st, K_RICCATI); launch_variant(h, B, first, pass, st, K_RICCATI); }
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, h->W, B, pass);
     { ProfScope ps(h, st, K_STEP); launch_variant(h, B, first, pass, st, K_STEP); }
     if (pass + 1 == next_check && max_passes_override <= 0) {
       HIPCHK(hipMemcpyAsync(h->h_active, h->W.active_hist + pass, sizeof(int), hipMemcpyDeviceToHost, st));

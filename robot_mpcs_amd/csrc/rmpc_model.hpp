@@ -63,21 +63,23 @@ constexpr int kMaxSlots = 4;   // distinct points (frame, or frame pair) the FK 
 constexpr int kMaxFkRows = 40;
 constexpr int kVarRows = 4;    // single-variable rows per variable: limit lower/upper, bound lower/upper
 struct DevTables {
+  // All fields are 32-bit (or double): sub-dword fields cannot be fetched through the scalar
+  // cache on gfx950 and would turn every table access into a vector-memory round trip.
   // kinematic slots: slot 0 is the goal's end frame when GoalReaching is present
   int nslots;
   int slot_fa[kMaxSlots], slot_fb[kMaxSlots];        // frame A, frame B (-1: single frame)
   int slot_row_begin[kMaxSlots + 1];                 // FK rows sorted by slot
   int nfkrows;
-  int16_t fk_row[kMaxFkRows];                        // storage index of the row (YAML order)
-  int8_t fk_kind[kMaxFkRows], fk_obst[kMaxFkRows], fk_mod[kMaxFkRows], fk_first[kMaxFkRows];
-  int16_t fk_idx[kMaxFkRows];                        // index among the FK rows (Jq storage)
+  int fk_row[kMaxFkRows];                            // storage index of the row (YAML order)
+  int fk_kind[kMaxFkRows], fk_obst[kMaxFkRows], fk_mod[kMaxFkRows], fk_first[kMaxFkRows];
+  int fk_idx[kMaxFkRows];                            // index among the FK rows (Jq storage)
   // rows that depend on one variable only, grouped by variable
-  int16_t v_row[RMPC_NV_MAX][kVarRows];              // storage index or -1
-  int8_t v_sgn[RMPC_NV_MAX][kVarRows];               // +1: z - limit, -1: limit - z
-  int16_t v_poff[RMPC_NV_MAX][kVarRows];             // parameter offset of the limit, -1: constant bound
-  int8_t v_soft[RMPC_NV_MAX][kVarRows];              // general row (softened when ns = 1)
-  int8_t v_mod[RMPC_NV_MAX][kVarRows];               // owning module, -1 for simple bounds
-  int8_t v_first[RMPC_NV_MAX][kVarRows];             // first row of its module (inverse-barrier objective)
+  int v_row[RMPC_NV_MAX][kVarRows];                  // storage index or -1
+  int v_sgn[RMPC_NV_MAX][kVarRows];                  // +1: z - limit, -1: limit - z
+  int v_poff[RMPC_NV_MAX][kVarRows];                 // parameter offset of the limit, -1: constant bound
+  int v_soft[RMPC_NV_MAX][kVarRows];                 // general row (softened when ns = 1)
+  int v_mod[RMPC_NV_MAX][kVarRows];                  // owning module, -1 for simple bounds
+  int v_first[RMPC_NV_MAX][kVarRows];                // first row of its module (inverse-barrier objective)
   double v_val[RMPC_NV_MAX][kVarRows];               // constant bound value
 };
 
