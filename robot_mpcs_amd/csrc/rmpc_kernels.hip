@@ -45,6 +45,7 @@ constexpr double kMuDiverged = 1e12;
 constexpr double kCurvMu = 1e-2; // curvature terms only once the barrier parameter is this small
 constexpr int kLsCurv = 2;        // trials granted to a step computed with constraint curvature
 constexpr int kCurvFailMax = 2;   // consecutive curvature-step failures before Gauss-Newton is latched
+constexpr int kGroupedMin = 512;    // list length from which the grouped Riccati blocks are used
 constexpr double kAccFeas = 1e-6; // acceptable termination: feasibility / complementarity level
 
 enum Status : int { ST_ACTIVE = 100 };
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(1024) void k_compact(Ws W, int B, int pass) {
   }
   const int total = sums[1023];
   // while most instances are still iterating the identity list keeps every access coalesced
-  const bool dense = (total * 4 > B);
+  const bool dense = (total * 8 > B);
   int base = dense ? lo : sums[tid] - cnt;
   for (int b = lo; b < hi; b++)
     if (dense || W.status[b] == ST_ACTIVE) W.act_idx[base++] = b;
@@ -624,20 +625,21 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const DevTables
 //                       P = sym(Qxx + Qxw K), p = qx + Qxw kff
 //   forward, stage k:   dw = K dx + kff, nu+ = P dx + p, dx+ = [A|B][dx; dw] + rc
 template <int NW>
-__device__ __forceinline__ void chol_solve(const double (&L)[NW][NW], double (&v)[NW]) {
+__device__ __forceinline__ void chol_solve(const double (&L)[NW][NW], const double (&invd)[NW], double (&v)[NW]) {
+  // L L^T x = v with the reciprocals of the diagonal supplied (no divisions on the chain)
 #pragma unroll
   for (int i = 0; i < NW; i++) {
     double s = v[i];
 #pragma unroll
     for (int l = 0; l < i; l++) s -= L[i][l] * v[l];
-    v[i] = s / L[i][i];
+    v[i] = s * invd[i];
   }
 #pragma unroll
   for (int i = NW - 1; i >= 0; i--) {
     double s = v[i];
 #pragma unroll
     for (int l = i + 1; l < NW; l++) s -= L[l][i] * v[l];
-    v[i] = s / L[i][i];
+    v[i] = s * invd[i];
   }
 }
 
@@ -667,17 +669,25 @@ __device__ __forceinline__ double wave_min(double v) {
   return v;
 }
 
-template <class C>
-__global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, const int B, const int first,
+template <class C, int IPB>
+__global__ __launch_bounds__(64 * IPB) void k_riccati(const DevModel M, const Ws W, const int B, const int first,
                                                 const int pass) {
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV, NW = C::NW;
   constexpr bool DD = (C::ROBOT == RMPC_ROBOT_DIFFDRIVE);
   constexpr int NP2 = NX * (NX + 1) / 2;
-  const int li = blockIdx.x;
-  if (li >= *W.n_act) return;
+  // IPB wavefronts per block work on IPB consecutive list entries: neighbouring instances share
+  // the 128-byte lines of the batch-minor arrays, so most of a wave's requests hit the CU's L1
+  // Two instantiations are launched every pass and pick their regime from the list length:
+  // the grouped one (IPB = C::IPB) while many instances iterate, the one-wave blocks (IPB = 1,
+  // static LDS addresses, lowest latency) in the iteration tail.
+  const int nact = *W.n_act;
+  if ((IPB > 1) != (nact >= kGroupedMin)) return;
+  const int wv = threadIdx.x >> 6;
+  const int li = blockIdx.x * IPB + wv;
+  if (li >= nact) return;
   const int b = W.act_idx[li];
   if (W.status[b] != ST_ACTIVE) return;  // uniform: one instance per wavefront
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int N = M.N;
   (void)B;
 
@@ -818,8 +828,11 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
   const double cwt = usec ? 1.0 : 0.0;  // Cqq is zero-filled when the model does not use it
 
   // ---- LDS images -------------------------------------------------------------------------
-  __shared__ double sP[NX * NX], sp[NX], sAB[NX * NV], sQ[NV * NV], sq[NV], sT[NX * NV], sPc[NX], src[NX];
-  __shared__ double sK[NW * NX], skf[NW], sdx[NX], sdw[NW];
+  constexpr int LDSW = NX * NX + NX + NX * NV + NV * NV + NV + NX * NV + NX + NX + NW * NX + NW + NX + NW;
+  __shared__ double lds[IPB][LDSW];
+  double *const sP = lds[wv], *const sp = sP + NX * NX, *const sAB = sp + NX, *const sQ = sAB + NX * NV,
+               *const sq = sQ + NV * NV, *const sT = sq + NV, *const sPc = sT + NX * NV, *const src = sPc + NX,
+               *const sK = src + NX, *const skf = sK + NW * NX, *const sdx = skf + NW, *const sdw = sdx + NX;
   const double h = M.dt, h2 = 0.5 * M.dt * M.dt;
 
   // [A | B] of the holonomic chain is constant: A = [I hI; 0 I], B = [h2 I; h I] on the u columns
@@ -930,6 +943,48 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
     if (k > 0) fetch_stage(k - 1);  // requests for the next stage travel while this one is computed
     WSYNC();
     if (k < N - 1) {
+      if constexpr (!DD) {
+        // Holonomic chain: A = [I hI; 0 I], B = [h2 I; h I].  [A|B]^T P [A|B] in closed form,
+        // each entry from at most four entries of P (blocks 11, 12, 21, 22 at (ii, jj)).
+#pragma unroll
+        for (int u = 0; u < EPL; u++) {
+          const int e = lane + 64 * u;
+          if (e < NV * NV) {
+            const int i = e / NV, j = e - i * NV;
+            // row / column kind: 0 = q, 1 = v, 2 = u, 3 = slack (no contribution)
+            const int ki = i < NQ ? 0 : (i < NX ? 1 : (i >= NX + NS ? 2 : 3));
+            const int kj = j < NQ ? 0 : (j < NX ? 1 : (j >= NX + NS ? 2 : 3));
+            if (ki != 3 && kj != 3) {
+              const int ii = ki == 0 ? i : (ki == 1 ? i - NQ : i - NX - NS);
+              const int jj = kj == 0 ? j : (kj == 1 ? j - NQ : j - NX - NS);
+              const double p11 = sP[ii * NX + jj], p12 = sP[ii * NX + NQ + jj];
+              const double p21 = sP[(NQ + ii) * NX + jj], p22 = sP[(NQ + ii) * NX + NQ + jj];
+              // left factor: row kind picks the combination of the two block rows
+              //   q: (r1, r2) = (1, 0); v: (h, 1); u: (h2, h)       (rows of [A|B]^T)
+              const double l1 = ki == 0 ? 1.0 : (ki == 1 ? h : h2), l2 = ki == 0 ? 0.0 : (ki == 1 ? 1.0 : h);
+              const double c1 = kj == 0 ? 1.0 : (kj == 1 ? h : h2), c2 = kj == 0 ? 0.0 : (kj == 1 ? 1.0 : h);
+              // sum_{a,b in {1,2}} l_a c_b P_ab
+              sQ[e] += l1 * (c1 * p11 + c2 * p12) + l2 * (c1 * p21 + c2 * p22);
+            }
+          }
+        }
+        if (lane < NX) {
+          double s = sp[lane];
+#pragma unroll
+          for (int l = 0; l < NX; l++) s += sP[lane * NX + l] * src[l];
+          sPc[lane] = s;
+        }
+        WSYNC();
+        if (lane < NV) {
+          const int ki = lane < NQ ? 0 : (lane < NX ? 1 : (lane >= NX + NS ? 2 : 3));
+          if (ki != 3) {
+            const int ii = ki == 0 ? lane : (ki == 1 ? lane - NQ : lane - NX - NS);
+            const double l1 = ki == 0 ? 1.0 : (ki == 1 ? h : h2), l2 = ki == 0 ? 0.0 : (ki == 1 ? 1.0 : h);
+            sq[lane] += l1 * sPc[ii] + l2 * sPc[NQ + ii];
+          }
+        }
+        WSYNC();
+      } else {
       // -- T = P [A|B], Pc = P rc + p ---------------------------------------------------------
 #pragma unroll
       for (int u = 0; u < TPL; u++) {
@@ -968,18 +1023,22 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
         sq[lane] = s;
       }
       WSYNC();
+      }
     }
     // -- Cholesky of Qww: every lane factors the small block in registers --------------------------
-    double L[NW][NW];
+    double L[NW][NW], invd[NW];
 #pragma unroll
     for (int j = 0; j < NW; j++) {
       double dg = sQ[(NX + j) * NV + NX + j];
 #pragma unroll
       for (int l = 0; l < j; l++) dg -= L[j][l] * L[j][l];
       if (!(dg > 0.0)) chol_ok = false;
-      dg = sqrt(dg);
-      L[j][j] = dg;
-      const double inv = 1.0 / dg;
+      // 1/sqrt(dg): hardware estimate + two Newton steps (full double precision), then sqrt = dg * rsqrt
+      double inv = __builtin_amdgcn_rsq(dg);
+      inv = inv * (1.5 - 0.5 * dg * inv * inv);
+      inv = inv * (1.5 - 0.5 * dg * inv * inv);
+      L[j][j] = dg * inv;
+      invd[j] = inv;
 #pragma unroll
       for (int i = j + 1; i < NW; i++) {
         double s = sQ[(NX + i) * NV + NX + j];
@@ -993,7 +1052,7 @@ __global__ __launch_bounds__(64) void k_riccati(const DevModel M, const Ws W, co
       double col[NW];
 #pragma unroll
       for (int i = 0; i < NW; i++) col[i] = (lane < NX) ? -sQ[(NX + i) * NV + lane] : -sq[NX + i];
-      chol_solve<NW>(L, col);
+      chol_solve<NW>(L, invd, col);
       if (lane < NX) {
 #pragma unroll
         for (int i = 0; i < NW; i++) { sK[i * NX + lane] = col[i]; W.Kg[IDX(i * NX + lane, k, b)] = col[i]; }
@@ -1574,7 +1633,11 @@ template <class C>
 static void launch_pass(rmpc_handle *h, int B, int first, int pass, hipStream_t st, int which) {
   const int lanes = h->Bp * h->M.N;
   if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, h->W, B, first);
-  else if (which == K_RICCATI) hipLaunchKernelGGL((k_riccati<C>), dim3(B), dim3(64), 0, st, h->M, h->W, B, first, pass);
+  else if (which == K_RICCATI) {
+    hipLaunchKernelGGL((k_riccati<C, C::IPB>), dim3((B + C::IPB - 1) / C::IPB), dim3(64 * C::IPB), 0, st, h->M, h->W, B, first, pass);
+    const int tail_blocks = B < kGroupedMin ? B : kGroupedMin;
+    hipLaunchKernelGGL((k_riccati<C, 1>), dim3(tail_blocks), dim3(64), 0, st, h->M, h->W, B, first, pass);
+  }
   else hipLaunchKernelGGL((k_step<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, h->W, B);
 }
 

@@ -105,6 +105,8 @@ struct Cfg {
   static constexpr int NQ2 = NQ_ * (NQ_ + 1) / 2;
   static constexpr int NR = 5;  // reduced diff-drive state (x, y, theta, v, omega)
   static constexpr bool CURV = (ROBOT_ == RMPC_ROBOT_CHAIN) && (NS_ == 0) && (NQ_ <= 3);
+  // instances (wavefronts) per block of the Riccati kernel: neighbours share cache lines
+  static constexpr int IPB = (NX > 8) ? 8 : 16;
 };
 
 // ---------------------------------------------------------------------------
