@@ -145,6 +145,43 @@ const char *rmpc_kernel_name(int idx);
 /* number of sweep/riccati/step passes of the last solve, and instance-iterations */
 int rmpc_last_passes(rmpc_handle *h);
 
+/* ---- next rows of the hot path: inputs produced on the device ---------- */
+
+/* Compact scene of B instances; every pointer is a DEVICE pointer and may be NULL (field left at
+ * zero).  Device counterpart of MPCPlanner.reset() + setGoalReaching / setRadialConstraints /
+ * setLinearConstraints / setJointLimits / setInputLimits / setVelLimits / setConstraintAvoidance /
+ * updateDynamicObstacles (robotmpcs/planner/mpcPlanner.py:83-210). */
+typedef struct rmpc_scene {
+  int32_t struct_size;        /* sizeof(rmpc_scene) */
+  const double *goal;         /* [B][3]            setGoalReaching, zero padded (:197-204) */
+  const double *r_body;       /* [B]               (:122,137,165) */
+  const double *obst;         /* [B][nobst][4]     static obstacles: position, radius (:120-133) */
+  const double *obst_dyn;     /* [B][nobst][9]     position, velocity, acceleration; stage k predicted at dt*k (:144-161) */
+  double dyn_radius;          /*                   radius of the predicted obstacles, self._r = 0.1 (:121) */
+  const double *lower_limits, *upper_limits;         /* [B][n]   (:167-175) */
+  const double *lower_limits_u, *upper_limits_u;     /* [B][nu]  (:187-195) */
+  const double *lower_limits_vel, *upper_limits_vel; /* [B][2]   (:177-185) */
+  const double *lin_constrs;  /* [B][N][nobst][4]  planes per stage (:135-141) */
+  double w, wu, ws;           /*                   weights["w"], ["wu"], ["ws"], broadcast by reset() (:92-104) */
+  double wconstr[RMPC_MAX_MODULES]; /*             weights["wconstr"] (:206-210) */
+} rmpc_scene;
+
+/* all_parameters [B][N][npar] (ABI layout) from a scene; bit-identical to the host packer. */
+int rmpc_pack_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene, double *d_params, void *stream);
+
+/* rmpc_solve_batch_device with the parameters expanded from a scene straight into the solver's
+ * workspace: the B*N*npar array never exists in the ABI layout. */
+int rmpc_solve_batch_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene, const double *d_xinit,
+                                  const double *d_x0, double *d_z_out, int32_t *d_exitflag, int32_t *d_iters,
+                                  double *d_kkt_res, double *d_obj, void *stream);
+
+/* Closed loop between two solves, on the device: xinit <- Phi(xinit, u_1 of the previous plan)
+ * with the model's own ERK2 map (the plant of the examples' env.step), and the warm start
+ * x0 <- shifted plan (shiftHorizon, mpcPlanner.py:215-226) when previous_plan != 0, else the new
+ * state repeated over the horizon with zero controls (setX0 "current_state", :228-232). */
+int rmpc_advance_device(rmpc_handle *h, int B, const double *d_z_prev, double *d_xinit, double *d_x0,
+                        int previous_plan, void *stream);
+
 /* Debug / parity hooks (used by tests through the same ABI): evaluate one
  * stage-parallel sweep at z = x0 (first-pass semantics) and return the
  * condensed stage blocks in instance-major order.

@@ -122,20 +122,29 @@ def module_rows(desc, z, p):
     return out
 
 
-def stage_ineq(desc, z, p, with_bounds=True):
+def stage_ineq(desc, z, p, with_bounds=True, fixed_state=False):
+    """fixed_state: stage 1 (x pinned to xinit) -- state-only, unsoftened rows are constants of
+    the problem and are neutralised (value 1), exactly as in rmpc_oracle.c."""
     q, x, s, u = split(desc, z)
-    rows = [r for mod in module_rows(desc, z, p) for r in mod]
+    mods = module_rows(desc, z, p)
+    if fixed_state and not desc["ns"]:
+        mods = [[1.0] * len(rows) if kind != INPUTLIM else rows for kind, rows in zip(desc["module_kind"], mods)]
+    rows = [r for mod in mods for r in mod]
     g = np.array(rows, dtype=float)
     if desc["ns"]:
         g = g + s
     if with_bounds:
         nv = desc["nx"] + desc["ns"] + desc["nu"]
         lb, ub = np.asarray(desc["lb"][:nv], dtype=float), np.asarray(desc["ub"][:nv], dtype=float)
-        g = np.concatenate([g, (z - lb)[np.isfinite(lb)], (ub - z)[np.isfinite(ub)]])
+        lo, hi = (z - lb), (ub - z)
+        if fixed_state:
+            lo[: desc["nx"]] = 1.0
+            hi[: desc["nx"]] = 1.0
+        g = np.concatenate([g, lo[np.isfinite(lb)], hi[np.isfinite(ub)]])
     return g
 
 
-def stage_cost(desc, z, p):
+def stage_cost(desc, z, p, fixed_state=False):
     q, x, s, u = split(desc, z)
     J = 0.0
     if desc["has_goal"]:
@@ -144,7 +153,7 @@ def stage_cost(desc, z, p):
     if desc["has_avoid"]:
         for i, rows in enumerate(module_rows(desc, z, p)):
             w = p[desc["off_wconstr"] + i]
-            if rows and w != 0.0:
+            if rows and w != 0.0 and not (fixed_state and desc["module_kind"][i] != INPUTLIM):
                 J += desc["N"] * w / rows[0]
     wu = p[desc["off_wu"]: desc["off_wu"] + desc["nu"]]
     J += float(u @ (wu * u))
@@ -194,7 +203,7 @@ class HorizonNLP:
 
     def objective(self, y):
         Z = self.unpack(y)
-        return sum(stage_cost(self.d, Z[k], self.P[k]) for k in range(self.N))
+        return sum(stage_cost(self.d, Z[k], self.P[k], fixed_state=(k == 0)) for k in range(self.N))
 
     def eq(self, y):
         Z = self.unpack(y)
@@ -206,7 +215,8 @@ class HorizonNLP:
 
     def ineq(self, y):
         Z = self.unpack(y)
-        return np.concatenate([stage_ineq(self.d, Z[k], self.P[k], with_bounds=False) for k in range(self.N)])
+        return np.concatenate([stage_ineq(self.d, Z[k], self.P[k], with_bounds=False, fixed_state=(k == 0))
+                               for k in range(self.N)])
 
     def bounds(self):
         nv = self.nv

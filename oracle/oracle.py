@@ -76,7 +76,7 @@ def lib():
         dp = C.POINTER(C.c_double)
         L.orc_desc_size.restype = C.c_int
         L.orc_eval_stage.restype = C.c_int
-        L.orc_eval_stage.argtypes = [C.POINTER(OrcDesc), dp, dp, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp]
+        L.orc_eval_stage.argtypes = [C.POINTER(OrcDesc), dp, dp, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, C.c_int]
         L.orc_num_rows.restype = C.c_int
         L.orc_num_rows.argtypes = [C.POINTER(OrcDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_fk.restype = C.c_int
@@ -156,7 +156,7 @@ class Oracle:
         assert rc == 0, rc
         return pos, J
 
-    def eval_stage(self, z, p, derivs=True, dynamics=True):
+    def eval_stage(self, z, p, derivs=True, dynamics=True, fixed_state=False):
         z = np.ascontiguousarray(z, dtype=np.float64); p = np.ascontiguousarray(p, dtype=np.float64)
         nv, nx, nw = self.nv, self.nx, self.nw
         MR = 64 + 2 * NV_MAX
@@ -164,7 +164,8 @@ class Oracle:
         xn = np.zeros(nx); A = np.zeros((nx, nx)); Bm = np.zeros((nx, nw))
         r = lib().orc_eval_stage(C.byref(self.cd), _p(z), _p(p), 1 if derivs else 0, _p(f),
                                  _p(gf) if derivs else None, _p(H) if derivs else None, _p(g),
-                                 _p(Jg) if derivs else None, _p(xn) if dynamics else None, _p(A), _p(Bm))
+                                 _p(Jg) if derivs else None, _p(xn) if dynamics else None, _p(A), _p(Bm),
+                                 1 if fixed_state else 0)
         m = self.m
         return dict(rows=r, f=f[0], gf=gf, H=H, g=g[:m].copy(), Jg=Jg[:m].copy(), xnext=xn, A=A, B=Bm)
 

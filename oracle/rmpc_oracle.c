@@ -245,9 +245,14 @@ static __thread double tl_C[ORC_NH_MAX][64];   /* n x n curvature matrix per gen
 static __thread double tl_cw[ORC_NH_MAX];      /* extra weight from the inverse-barrier objective */
 
 
+/* fixed_state != 0 (stage 1, whose state is pinned to xinit): rows that depend on the state
+ * only and are not softened are constants of the problem -- they are neutralised (value 1,
+ * zero gradient, no inverse-barrier term), the standard presolve for constraints on fixed
+ * variables.  Without it a start state that sits on a constraint boundary (every closed loop
+ * whose previous plan had an active state constraint) makes the NLP infeasible by rounding. */
 int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
                    int want, double *f_out, double *gf, double *H, double *g,
-                   double *Jg, double *xnext, double *A, double *Bm) {
+                   double *Jg, double *xnext, double *A, double *Bm, int fixed_state) {
   const int n = d->n, nx = d->nx, ns = d->ns, nu = d->nu, nv = nx + ns + nu, nw = ns + nu;
   const double *q = z;
   const double *u = z + nx + ns;
@@ -415,8 +420,19 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
     } else {
       return -3;
     }
+    const int x_only = (kind != ORC_MOD_INPUTLIMIT);
+    const int neutral = fixed_state && x_only && !ns;
+    if (neutral) {
+      for (int r = row0; r < row; r++) {
+        g[r] = 1.0;
+        if (want) {
+          for (int a = 0; a < nv; a++) Jg[r * nv + a] = 0.0;
+          memset(tl_C[r], 0, sizeof tl_C[r]);
+        }
+      }
+    }
     /* --- ConstraintAvoidance (constraint_avoidance.py:22-31): N * w_i / h_first --- */
-    if (d->has_avoid && row > row0) {
+    if (d->has_avoid && row > row0 && !(fixed_state && x_only)) {
       double wi = p[d->off_wconstr + mi];
       if (wi != 0.0) {
         double c = (double)d->N * wi;
@@ -447,14 +463,16 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
   /* simple bounds lb <= z <= ub (mpcModel.py:91-104) */
   for (int j = 0; j < nv; j++)
     if (isfinite(d->lb[j])) {
-      g[row] = z[j] - d->lb[j];
-      if (want) Jg[row * nv + j] = 1.0;
+      const int neutral = fixed_state && j < nx;
+      g[row] = neutral ? 1.0 : z[j] - d->lb[j];
+      if (want && !neutral) Jg[row * nv + j] = 1.0;
       row++;
     }
   for (int j = 0; j < nv; j++)
     if (isfinite(d->ub[j])) {
-      g[row] = d->ub[j] - z[j];
-      if (want) Jg[row * nv + j] = -1.0;
+      const int neutral = fixed_state && j < nx;
+      g[row] = neutral ? 1.0 : d->ub[j] - z[j];
+      if (want && !neutral) Jg[row * nv + j] = -1.0;
       row++;
     }
   /* dynamics */
@@ -533,7 +551,7 @@ static int eval_all(const orc_desc *d, orc_work *w, const double *params) {
     int r = orc_eval_stage(d, w->z + (size_t)k * nv, params + (size_t)k * d->npar, 1, &w->f[k],
                            w->gf + (size_t)k * nv, w->H + (size_t)k * nv * nv, w->g + (size_t)k * MRM,
                            w->Jg + (size_t)k * MRM * nv, k < N - 1 ? w->xn + (size_t)k * nx : 0,
-                           w->A + (size_t)k * nx * nx, w->Bm + (size_t)k * nx * nw);
+                           w->A + (size_t)k * nx * nx, w->Bm + (size_t)k * nx * nw, k == 0);
     memcpy(w->Cc + (size_t)k * ORC_NH_MAX * 64, tl_C, sizeof tl_C);
     memcpy(w->cw + (size_t)k * ORC_NH_MAX, tl_cw, sizeof tl_cw);
     if (r == ORC_EVAL_BAD_AVOID) rc = ORC_EVAL_BAD_AVOID;
@@ -707,7 +725,7 @@ static int trial_merit(const orc_desc *d, orc_work *w, const double *params, dou
   for (int k = 0; k < N; k++) {
     double fk;
     int r = orc_eval_stage(d, w->zt + (size_t)k * nv, params + (size_t)k * d->npar, 0, &fk, 0, 0,
-                           w->gt + (size_t)k * MRM, 0, k < N - 1 ? w->xnt + (size_t)k * nx : 0, 0, 0);
+                           w->gt + (size_t)k * MRM, 0, k < N - 1 ? w->xnt + (size_t)k * nx : 0, 0, 0, k == 0);
     if (r < 0) return 1;
     f += fk;
     for (int i = 0; i < m; i++) {

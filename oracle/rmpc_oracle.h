@@ -102,10 +102,12 @@ typedef struct orc_desc {
  * H is the generalised Gauss-Newton Hessian of the stage cost.
  * g holds the general rows (YAML order, slack added when ns==1) followed by
  * the finite lower bounds (z-lb) and the finite upper bounds (ub-z).
+ * fixed_state != 0: stage 1 (state pinned to xinit), state-only unsoftened rows are
+ * neutralised (value 1, zero gradient, no inverse-barrier term).
  * Returns the number of rows m, or <0 on error. */
 int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
                    int want_derivs, double *f, double *gf, double *H,
-                   double *g, double *Jg, double *xnext, double *A, double *Bm);
+                   double *g, double *Jg, double *xnext, double *A, double *Bm, int fixed_state);
 
 /* number of general rows nh and total rows m (incl. finite bounds) */
 int orc_num_rows(const orc_desc *d, int *nh, int *m);

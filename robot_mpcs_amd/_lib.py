@@ -52,11 +52,27 @@ class RmpcDesc(C.Structure):
     ]
 
 
+class RmpcScene(C.Structure):
+    """Mirror of ``rmpc_scene`` (include/rmpc.h): device pointers + broadcast weights."""
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("goal", C.c_void_p), ("r_body", C.c_void_p), ("obst", C.c_void_p), ("obst_dyn", C.c_void_p),
+        ("dyn_radius", C.c_double),
+        ("lower_limits", C.c_void_p), ("upper_limits", C.c_void_p),
+        ("lower_limits_u", C.c_void_p), ("upper_limits_u", C.c_void_p),
+        ("lower_limits_vel", C.c_void_p), ("upper_limits_vel", C.c_void_p),
+        ("lin_constrs", C.c_void_p),
+        ("w", C.c_double), ("wu", C.c_double), ("ws", C.c_double),
+        ("wconstr", C.c_double * MAX_MODULES),
+    ]
+
+
 # every symbol include/rmpc.h declares
 EXPORTED_SYMBOLS = [
     "rmpc_version", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
     "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_profiling", "rmpc_get_profile",
     "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep",
+    "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_advance_device",
 ]
 
 _lib = None
@@ -103,6 +119,12 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_last_passes.argtypes = [C.c_void_p]
     L.rmpc_debug_sweep.restype = C.c_int
     L.rmpc_debug_sweep.argtypes = [C.c_void_p, C.c_int] + [dp] * 9
+    L.rmpc_pack_scene_device.restype = C.c_int
+    L.rmpc_pack_scene_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(RmpcScene), C.c_void_p, C.c_void_p]
+    L.rmpc_solve_batch_scene_device.restype = C.c_int
+    L.rmpc_solve_batch_scene_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(RmpcScene)] + [C.c_void_p] * 8
+    L.rmpc_advance_device.restype = C.c_int
+    L.rmpc_advance_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     if L.rmpc_desc_size() != C.sizeof(RmpcDesc):
         raise RmpcError("rmpc_desc layout mismatch between _lib.py and librmpc_hip.so")
     _lib = L
@@ -219,6 +241,41 @@ class Solver:
         rc = self._L.rmpc_solve_batch_device(self._h, int(B), ptr(xinit), ptr(x0), ptr(params), ptr(z_out),
                                              ptr(exitflag), ptr(iters), ptr(kkt), ptr(obj), st)
         self._check(rc, "rmpc_solve_batch_device")
+
+    # -- scenes and closed loop on the device ----------------------------
+    def make_scene(self, weights: dict, dyn_radius: float = 0.1, **tensors) -> RmpcScene:
+        """``tensors``: goal, r_body, obst, obst_dyn, lower_limits, upper_limits, lower_limits_u,
+        upper_limits_u, lower_limits_vel, upper_limits_vel, lin_constrs -- contiguous fp64 device
+        tensors (anything with ``data_ptr()``).  ``weights`` = the YAML ``mpc.weights`` block."""
+        s = RmpcScene()
+        s.struct_size = C.sizeof(RmpcScene)
+        for name, t in tensors.items():
+            setattr(s, name, C.c_void_p(t.data_ptr()))
+        s.dyn_radius = float(dyn_radius)
+        s.w = float(weights.get("w", 0.0)); s.wu = float(weights.get("wu", 0.0)); s.ws = float(weights.get("ws", 0.0))
+        wc = list(weights.get("wconstr", []))
+        for i in range(MAX_MODULES):
+            s.wconstr[i] = float(wc[i]) if i < len(wc) else 0.0
+        s._keepalive = tensors  # the struct only holds raw pointers
+        return s
+
+    def pack_scene_device(self, B, scene: RmpcScene, params_out, stream=None):
+        st = C.c_void_p(int(stream)) if stream else C.c_void_p(0)
+        rc = self._L.rmpc_pack_scene_device(self._h, int(B), C.byref(scene), C.c_void_p(params_out.data_ptr()), st)
+        self._check(rc, "rmpc_pack_scene_device")
+
+    def solve_scene_device(self, B, scene: RmpcScene, xinit, x0, z_out, exitflag, iters, kkt, obj, stream=None):
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        st = C.c_void_p(int(stream)) if stream else C.c_void_p(0)
+        rc = self._L.rmpc_solve_batch_scene_device(self._h, int(B), C.byref(scene), ptr(xinit), ptr(x0), ptr(z_out),
+                                                   ptr(exitflag), ptr(iters), ptr(kkt), ptr(obj), st)
+        self._check(rc, "rmpc_solve_batch_scene_device")
+
+    def advance_device(self, B, z_prev, xinit, x0, previous_plan: bool, stream=None):
+        st = C.c_void_p(int(stream)) if stream else C.c_void_p(0)
+        rc = self._L.rmpc_advance_device(self._h, int(B), C.c_void_p(z_prev.data_ptr()), C.c_void_p(xinit.data_ptr()),
+                                         C.c_void_p(x0.data_ptr()), 1 if previous_plan else 0, st)
+        self._check(rc, "rmpc_advance_device")
 
     def set_profiling(self, enable: bool):
         self._check(self._L.rmpc_set_profiling(self._h, 1 if enable else 0), "rmpc_set_profiling")

@@ -393,8 +393,16 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const DevTables
 #pragma unroll
         for (int a = 0; a < NQ; a++) gq[a] = dot(Pt, J[a]) * cinv;
       }
+      // stage 1 (state pinned to xinit): state-only, unsoftened rows are constants of the
+      // problem -- neutralised (value 1, zero gradient, no inverse-barrier term); DESIGN.md 2
+      if (k == 0 && NS == 0) {
+        h = 1.0;
+        cinv = 0.0;
+#pragma unroll
+        for (int a = 0; a < NQ; a++) gq[a] = 0.0;
+      }
       double cw = 0.0;
-      if (M.has_avoid && T.fk_first[r]) {
+      if (M.has_avoid && T.fk_first[r] && k != 0) {
         // inverse-barrier objective N w_i / h on the first row of a module (constraint_avoidance.py:22-31)
         const double wi = P(M.off_wconstr + mi);
         if (wi != 0.0) {
@@ -474,8 +482,9 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const DevTables
       if (i < 0) continue;  // uniform
       const double sg = (double)T.v_sgn[j][u];
       const bool soft = (NS > 0) && T.v_soft[j][u];
-      const double h = sg * (z[j] - lim[u]);
-      if (M.has_avoid && T.v_first[j][u]) {
+      const bool neutral = (k == 0) && (j < NX) && !soft;  // constant of the problem at the pinned stage
+      const double h = neutral ? 1.0 : sg * (z[j] - lim[u]);
+      if (M.has_avoid && T.v_first[j][u] && !(k == 0 && j < NX)) {
         const double wi = P(M.off_wconstr + T.v_mod[j][u]);
         if (wi != 0.0) {
           const double cN = (double)M.N * wi;
@@ -491,6 +500,7 @@ __global__ __launch_bounds__(256) void k_sweep(const DevModel M, const DevTables
       if constexpr (NS > 0) { if (soft) g += sl; }
       if (T.v_poff[j][u] >= 0) W.grow[IDX(i, k, b)] = g;  // general rows keep their value for k_step
       const RowW rw = row_core(i, g, tcv[u], lcv[u], dtv[u], dlv[u]);
+      if (neutral) continue;
       q0[j] += sg * rw.ca;
       q1[j] += sg * rw.cb;
       rs[j] -= sg * rw.lv;
@@ -1255,7 +1265,7 @@ __global__ __launch_bounds__(256) void k_step(const DevModel M, const DevTables 
       tv[u] = tc[IDX(ii, k, b)];
       lv[u] = lc[IDX(ii, k, b)];
       const double gl = grow[IDX(general ? ii : 0, k, b)];
-      gv[u] = general ? gl : (double)T.v_sgn[j][u] * (z[j] - T.v_val[j][u]);
+      gv[u] = general ? gl : ((k == 0 && j < NX) ? 1.0 : (double)T.v_sgn[j][u] * (z[j] - T.v_val[j][u]));
     }
 #pragma unroll
     for (int u = 0; u < kVarRows; u++) {
@@ -1270,6 +1280,114 @@ __global__ __launch_bounds__(256) void k_step(const DevModel M, const DevTables 
   atomicMin(&W.amin_p[b], (unsigned long long)__double_as_longlong(ap));
   atomicMin(&W.amin_d[b], (unsigned long long)__double_as_longlong(ad));
   W.gphi[(size_t)k * W.Bp + b] = gphi;
+}
+
+
+// ===========================================================================
+// Scene packing and closed-loop advance: device
+// counterparts of the planner's host loops, so that neither the N*npar
+// parameter vectors nor the plans have to cross PCIe between control steps.
+// ===========================================================================
+struct SceneDev {
+  const double *goal, *r_body, *obst, *obst_dyn, *lower, *upper, *lower_u, *upper_u, *lower_vel, *upper_vel, *lin;
+  double dyn_radius, w, wu, ws;
+  double wconstr[RMPC_MAX_MODULES];
+};
+struct SceneOff {
+  int r_body, obst, lin, lower, upper, lower_u, upper_u, lower_vel, upper_vel, wu, goal, wgoal, wconstr, ws;
+  int n, nu, nobst, n_modules, npar, N;
+  double dt;
+};
+
+// One lane per (instance, stage).  SOA = 0: ABI layout params[b][k][npar] (what
+// MPCPlanner.reset() + set*() + updateDynamicObstacles() produce, mpcPlanner.py:83-210);
+// SOA = 1: straight into the solver's batch-minor parameter array.
+template <int SOA>
+__global__ __launch_bounds__(256) void k_scene(const SceneDev S, const SceneOff O, double *__restrict__ out, int B, int Bp) {
+#pragma clang fp contract(off)
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  int b, k;
+  if (SOA) { b = gid % Bp; k = gid / Bp; } else { k = gid % O.N; b = gid / O.N; }
+  if (b >= B || k >= O.N) return;
+  auto put = [&](int off, double v) __attribute__((always_inline)) {
+    if (SOA) out[((size_t)off * O.N + k) * Bp + b] = v;
+    else out[((size_t)b * O.N + k) * O.npar + off] = v;
+  };
+  // reset(): zeros, then the broadcast weights (mpcPlanner.py:91-104)
+  for (int j = 0; j < O.npar; j++) put(j, 0.0);
+  if (O.wgoal >= 0) for (int j = 0; j < 3; j++) put(O.wgoal + j, S.w);
+  for (int j = 0; j < O.nu; j++) put(O.wu + j, S.wu);
+  if (O.ws >= 0) put(O.ws, S.ws);
+  if (O.wconstr >= 0) for (int j = 0; j < O.n_modules; j++) put(O.wconstr + j, S.wconstr[j]);
+  if (O.goal >= 0 && S.goal) for (int j = 0; j < 3; j++) put(O.goal + j, S.goal[(size_t)b * 3 + j]);
+  if (O.r_body >= 0 && S.r_body) put(O.r_body, S.r_body[b]);
+  if (O.obst >= 0) {
+    if (S.obst_dyn) {
+      // updateDynamicObstacles (mpcPlanner.py:144-161): c = pos + (vel*dt)*k + (0.5*(dt*k)^2)*acc
+      const double kk = (double)k;
+      for (int j = 0; j < O.nobst; j++) {
+        const double *o = S.obst_dyn + ((size_t)b * O.nobst + j) * 9;
+        for (int c = 0; c < 3; c++) {
+          // every product and sum rounded separately (fp contraction is switched off for this
+          // kernel): bit-identical to the reference's numpy expression pos + vel*dt*i + 0.5*(dt*i)**2*acc
+          const double tk = O.dt * kk;
+          const double lin = (o[3 + c] * O.dt) * kk;
+          const double quad = (0.5 * (tk * tk)) * o[6 + c];
+          put(O.obst + 4 * j + c, (o[c] + lin) + quad);
+        }
+        put(O.obst + 4 * j + 3, S.dyn_radius);
+      }
+    } else if (S.obst) {
+      for (int j = 0; j < 4 * O.nobst; j++) put(O.obst + j, S.obst[(size_t)b * 4 * O.nobst + j]);
+    }
+  }
+  if (O.lin >= 0 && S.lin)
+    for (int j = 0; j < 4 * O.nobst; j++) put(O.lin + j, S.lin[((size_t)b * O.N + k) * 4 * O.nobst + j]);
+  if (O.lower >= 0 && S.lower) for (int j = 0; j < O.n; j++) put(O.lower + j, S.lower[(size_t)b * O.n + j]);
+  if (O.upper >= 0 && S.upper) for (int j = 0; j < O.n; j++) put(O.upper + j, S.upper[(size_t)b * O.n + j]);
+  if (O.lower_u >= 0 && S.lower_u) for (int j = 0; j < O.nu; j++) put(O.lower_u + j, S.lower_u[(size_t)b * O.nu + j]);
+  if (O.upper_u >= 0 && S.upper_u) for (int j = 0; j < O.nu; j++) put(O.upper_u + j, S.upper_u[(size_t)b * O.nu + j]);
+  if (O.lower_vel >= 0 && S.lower_vel) for (int j = 0; j < 2; j++) put(O.lower_vel + j, S.lower_vel[(size_t)b * 2 + j]);
+  if (O.upper_vel >= 0 && S.upper_vel) for (int j = 0; j < 2; j++) put(O.upper_vel + j, S.upper_vel[(size_t)b * 2 + j]);
+}
+
+// Closed loop between two solves: the plant is the model's own ERK2 map applied to the first
+// control of the previous plan, the warm start is the shifted plan (shiftHorizon,
+// mpcPlanner.py:215-226) or the current state repeated (setX0 "current_state", :228-232).
+template <class C>
+__global__ __launch_bounds__(256) void k_advance(const DevModel M, const double *__restrict__ zprev, double *__restrict__ xinit,
+                                                 double *__restrict__ x0, int B, int previous_plan) {
+  constexpr int NX = C::NX, NS = C::NS, NV = C::NV;
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const int N = M.N;
+  double z[NV], xn[NX];
+#pragma unroll
+  for (int j = 0; j < NX; j++) z[j] = xinit[(size_t)b * NX + j];
+#pragma unroll
+  for (int j = NX; j < NV; j++) z[j] = zprev[(size_t)b * N * NV + j];  // slack and first control of the plan
+  if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
+    chain_step<C>(M.dt, z, xn);
+  } else {
+    double A5[25], B5[10];
+    diffdrive_step<C>(M.dt, z, xn, A5, B5, false);
+  }
+#pragma unroll
+  for (int j = 0; j < NX; j++) xinit[(size_t)b * NX + j] = xn[j];
+  for (int k = 0; k < N; k++) {
+    double *o = x0 + ((size_t)b * N + k) * NV;
+    if (previous_plan) {
+      const double *s = zprev + ((size_t)b * N + (k + 1 < N ? k + 1 : N - 1)) * NV;
+#pragma unroll
+      for (int j = 0; j < NV; j++) o[j] = s[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NX; j++) o[j] = xn[j];
+#pragma unroll
+      for (int j = NX; j < NV; j++) o[j] = 0.0;
+    }
+  }
+  (void)NS;
 }
 
 }  // namespace rmpc
@@ -1698,7 +1816,8 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
   {
     ProfScope ps(h, st, K_PACK);
     dim3 g1((B + 63) / 64, (M.N * M.npar + 63) / 64);
-    hipLaunchKernelGGL(k_pack, g1, dim3(256), 0, st, d_params, h->W.p, B, M.N * M.npar, M.npar, M.N, h->Bp);
+    if (d_params)  // nullptr: the parameters were written straight into W.p by rmpc_solve_batch_scene_device
+      hipLaunchKernelGGL(k_pack, g1, dim3(256), 0, st, d_params, h->W.p, B, M.N * M.npar, M.npar, M.N, h->Bp);
     dim3 g2((B + 63) / 64, (M.N * M.nv + 63) / 64);
     hipLaunchKernelGGL(k_pack, g2, dim3(256), 0, st, d_x0, h->W.z[0], B, M.N * M.nv, M.nv, M.N, h->Bp);
     hipLaunchKernelGGL(k_init, dim3((B + 255) / 256), dim3(256), 0, st, h->W, d_xinit, B, M.nx, M.mu0);
@@ -1856,6 +1975,69 @@ int rmpc_solve_batch_device(rmpc_handle *h, int B, const double *d_xinit, const 
     return fail("null argument");
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   return solve_device(h, B, d_xinit, d_x0, d_params, d_z_out, d_exitflag, d_iters, d_kkt_res, d_obj, st, 0);
+}
+
+static void scene_args(const rmpc_handle *h, const rmpc_scene *s, SceneDev &S, SceneOff &O) {
+  const rmpc_desc &d = h->desc;
+  S.goal = s->goal; S.r_body = s->r_body; S.obst = s->obst; S.obst_dyn = s->obst_dyn;
+  S.lower = s->lower_limits; S.upper = s->upper_limits; S.lower_u = s->lower_limits_u; S.upper_u = s->upper_limits_u;
+  S.lower_vel = s->lower_limits_vel; S.upper_vel = s->upper_limits_vel; S.lin = s->lin_constrs;
+  S.dyn_radius = s->dyn_radius; S.w = s->w; S.wu = s->wu; S.ws = s->ws;
+  for (int i = 0; i < RMPC_MAX_MODULES; i++) S.wconstr[i] = s->wconstr[i];
+  O.r_body = d.off_r_body; O.obst = d.off_obst; O.lin = d.off_lin; O.lower = d.off_lower; O.upper = d.off_upper;
+  O.lower_u = d.off_lower_u; O.upper_u = d.off_upper_u; O.lower_vel = d.off_lower_vel; O.upper_vel = d.off_upper_vel;
+  O.wu = d.off_wu; O.goal = d.has_goal ? d.off_goal : -1; O.wgoal = d.has_goal ? d.off_wgoal : -1;
+  O.wconstr = d.has_avoid ? d.off_wconstr : -1; O.ws = d.ns ? d.off_ws : -1;
+  O.n = d.n; O.nu = d.nu; O.nobst = d.nobst; O.n_modules = d.n_modules; O.npar = d.npar; O.N = d.N; O.dt = d.dt;
+}
+
+int rmpc_pack_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene, double *d_params, void *stream) {
+  if (!h || !scene || !d_params) return fail("null argument");
+  if (scene->struct_size != (int)sizeof(rmpc_scene)) return fail("rmpc_scene size mismatch");
+  if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  SceneDev S; SceneOff O;
+  scene_args(h, scene, S, O);
+  const int lanes = B * h->M.N;
+  hipLaunchKernelGGL((k_scene<0>), dim3((lanes + 255) / 256), dim3(256), 0, st, S, O, d_params, B, h->Bp);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int rmpc_solve_batch_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene, const double *d_xinit,
+                                  const double *d_x0, double *d_z_out, int32_t *d_exitflag, int32_t *d_iters,
+                                  double *d_kkt_res, double *d_obj, void *stream) {
+  if (!h || !scene || !d_xinit || !d_x0 || !d_z_out || !d_exitflag || !d_iters || !d_kkt_res || !d_obj)
+    return fail("null argument");
+  if (scene->struct_size != (int)sizeof(rmpc_scene)) return fail("rmpc_scene size mismatch");
+  if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  SceneDev S; SceneOff O;
+  scene_args(h, scene, S, O);
+  const int lanes = h->Bp * h->M.N;
+  hipLaunchKernelGGL((k_scene<1>), dim3((lanes + 255) / 256), dim3(256), 0, st, S, O, h->W.p, B, h->Bp);
+  return solve_device(h, B, d_xinit, d_x0, nullptr, d_z_out, d_exitflag, d_iters, d_kkt_res, d_obj, st, 0);
+}
+
+int rmpc_advance_device(rmpc_handle *h, int B, const double *d_z_prev, double *d_xinit, double *d_x0,
+                        int previous_plan, void *stream) {
+  if (!h || !d_z_prev || !d_xinit || !d_x0) return fail("null argument");
+  if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  const dim3 g((B + 255) / 256), t(256);
+  switch (h->variant) {
+    case 0: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
+    case 1: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 3, 1>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
+    case 2: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 7, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
+    case 3: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 7, 1>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
+    case 4: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
+    case 5: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 int rmpc_set_profiling(rmpc_handle *h, int enable) {

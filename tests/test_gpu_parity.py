@@ -86,7 +86,7 @@ def test_sweep_blocks_match_oracle(rt, name):
     for b in range(B):
         P = sc.params[b].reshape(N, o.npar)
         for k in range(N):
-            e = o.eval_stage(sc.x0[b, k], P[k])
+            e = o.eval_stage(sc.x0[b, k], P[k], fixed_state=(k == 0))
             t = np.maximum(e["g"], 1e-2); lam = mu0 / t
             rg = e["g"] - t
             Q = e["H"] + e["Jg"].T @ np.diag(lam / t) @ e["Jg"]
@@ -153,7 +153,7 @@ def test_full_size_feasibility_against_oracle_rows(rt, name):
     for b in rng.choice(conv, size=24, replace=False):
         P = sc.params[b].reshape(o.N, o.npar)
         for k in range(o.N):
-            e = o.eval_stage(r["z"][b, k], P[k], derivs=False)
+            e = o.eval_stage(r["z"][b, k], P[k], derivs=False, fixed_state=(k == 0))
             assert e["g"].min() >= -2e-6
             if k < o.N - 1:
                 assert np.abs(e["xnext"] - r["z"][b, k + 1, : o.nx]).max() <= 2e-6
