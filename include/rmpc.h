@@ -182,6 +182,16 @@ int rmpc_solve_batch_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene
 int rmpc_advance_device(rmpc_handle *h, int B, const double *d_z_prev, double *d_xinit, double *d_x0,
                         int previous_plan, void *stream);
 
+/* Free-space decomposition on the device: for each of the B*N seed points
+ * (e.g. the planned lidar position of instance b at stage k) at most K half-planes
+ * [a(3), d] from instance b's point cloud of P <= 64 points, greedy nearest-point rule and dummy
+ * planes of robotmpcs/utils/free_space_decomposition.py:79-116.  d_points [B][P][3],
+ * d_seeds [B][N][3], d_planes [B][N][K][4] = the lin_constrs field of rmpc_scene
+ * (setLinearConstraints, mpcPlanner.py:135-141; called N times per control step by
+ * examples/boxer_example.py:193-203).  Needs no handle. */
+int rmpc_free_space_device(int B, int N, int P, int K, double max_radius, const double *d_points,
+                           const double *d_seeds, double *d_planes, void *stream);
+
 /* Debug / parity hooks (used by tests through the same ABI): evaluate one
  * stage-parallel sweep at z = x0 (first-pass semantics) and return the
  * condensed stage blocks in instance-major order.

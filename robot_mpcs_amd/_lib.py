@@ -72,7 +72,7 @@ EXPORTED_SYMBOLS = [
     "rmpc_version", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
     "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_profiling", "rmpc_get_profile",
     "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep",
-    "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_advance_device",
+    "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_advance_device", "rmpc_free_space_device",
 ]
 
 _lib = None
@@ -125,6 +125,8 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_solve_batch_scene_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(RmpcScene)] + [C.c_void_p] * 8
     L.rmpc_advance_device.restype = C.c_int
     L.rmpc_advance_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.rmpc_free_space_device.restype = C.c_int
+    L.rmpc_free_space_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     if L.rmpc_desc_size() != C.sizeof(RmpcDesc):
         raise RmpcError("rmpc_desc layout mismatch between _lib.py and librmpc_hip.so")
     _lib = L
@@ -183,6 +185,20 @@ def _dp(a):
 
 def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def free_space_decomposition_device(points, seeds, planes_out, max_radius: float, stream=None):
+    """points (B, P, 3), seeds (B, N, 3), planes_out (B, N, K, 4): contiguous fp64 device tensors.
+    Device counterpart of ``FreeSpaceDecomposition.compute_constraints`` + ``asdict`` of the
+    reference (``robotmpcs/utils/free_space_decomposition.py:79-116``) for B*N seeds at once."""
+    L = load_library()
+    B, P = int(points.shape[0]), int(points.shape[1])
+    N, K = int(seeds.shape[1]), int(planes_out.shape[2])
+    st = C.c_void_p(int(stream)) if stream else C.c_void_p(0)
+    rc = L.rmpc_free_space_device(B, N, P, K, float(max_radius), C.c_void_p(points.data_ptr()),
+                                  C.c_void_p(seeds.data_ptr()), C.c_void_p(planes_out.data_ptr()), st)
+    if rc != 0:
+        raise RmpcError("rmpc_free_space_device failed: " + L.rmpc_last_error().decode())
 
 
 class Solver:

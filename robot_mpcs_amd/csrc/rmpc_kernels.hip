@@ -1390,6 +1390,57 @@ __global__ __launch_bounds__(256) void k_advance(const DevModel M, const double 
   (void)NS;
 }
 
+// ===========================================================================
+// Free-space decomposition: lidar point cloud -> at most K half-planes
+// around a seed point, one lane per (instance, stage) seed.  Greedy rule of the reference
+// (robotmpcs/utils/free_space_decomposition.py:79-97): the closest remaining point inside
+// max_radius defines the plane through it with normal (seed - point); points on or behind the
+// plane are discarded; unused slots get the dummy plane of asdict() (:110-114).  The sort of
+// the reference is replaced by K arg-min sweeps over a keep-mask (P <= 64 points).
+// ===========================================================================
+__global__ __launch_bounds__(256) void k_fsd(const double *__restrict__ points, const double *__restrict__ seeds,
+                                             double *__restrict__ out, int B, int N, int P, int K, double max_radius) {
+#pragma clang fp contract(off)
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= B * N) return;
+  const int b = gid / N;
+  const double *pc = points + (size_t)b * P * 3;
+  const double s0 = seeds[(size_t)gid * 3], s1 = seeds[(size_t)gid * 3 + 1], s2 = seeds[(size_t)gid * 3 + 2];
+  double *o = out + (size_t)gid * K * 4;
+  unsigned long long keep = 0ull;
+  for (int i = 0; i < P; i++) {
+    const double d0 = pc[3 * i] - s0, d1 = pc[3 * i + 1] - s1, d2 = pc[3 * i + 2] - s2;
+    if (sqrt(d0 * d0 + d1 * d1 + d2 * d2) < max_radius) keep |= (1ull << i);
+  }
+  int nc = 0;
+  while (keep && nc < K) {
+    int best = -1;
+    double bd = 0.0;
+    for (int i = 0; i < P; i++)
+      if (keep & (1ull << i)) {
+        const double d0 = pc[3 * i] - s0, d1 = pc[3 * i + 1] - s1, d2 = pc[3 * i + 2] - s2;
+        const double dd = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        if (best < 0 || dd < bd) { best = i; bd = dd; }
+      }
+    const double p0 = pc[3 * best], p1 = pc[3 * best + 1], p2 = pc[3 * best + 2];
+    const double n0 = s0 - p0, n1 = s1 - p1, n2 = s2 - p2;
+    const double c = -((n0 * p0 + n1 * p1) + n2 * p2);
+    o[4 * nc] = n0; o[4 * nc + 1] = n1; o[4 * nc + 2] = n2; o[4 * nc + 3] = c;
+    nc++;
+    for (int i = 0; i < P; i++)
+      if (keep & (1ull << i)) {
+        const double v = ((n0 * pc[3 * i] + n1 * pc[3 * i + 1]) + n2 * pc[3 * i + 2]) + c;
+        if (v <= 0.0) keep &= ~(1ull << i);
+      }
+  }
+  for (; nc < K; nc++) {
+    // HalfPlane(seed + (20, 20, 0), seed): normal = seed - point
+    const double p0 = s0 + 20.0, p1 = s1 + 20.0, p2 = s2 + 0.0;
+    const double n0 = s0 - p0, n1 = s1 - p1, n2 = s2 - p2;
+    o[4 * nc] = n0; o[4 * nc + 1] = n1; o[4 * nc + 2] = n2; o[4 * nc + 3] = -((n0 * p0 + n1 * p1) + n2 * p2);
+  }
+}
+
 }  // namespace rmpc
 
 // ===========================================================================
@@ -2036,6 +2087,16 @@ int rmpc_advance_device(rmpc_handle *h, int B, const double *d_z_prev, double *d
     case 4: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
     case 5: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
   }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int rmpc_free_space_device(int B, int N, int P, int K, double max_radius, const double *d_points,
+                           const double *d_seeds, double *d_planes, void *stream) {
+  if (!d_points || !d_seeds || !d_planes) return fail("null argument");
+  if (B < 1 || N < 1 || K < 1 || P < 1 || P > 64) return fail("free space decomposition: need 1 <= P <= 64 points, K >= 1");
+  hipLaunchKernelGGL(k_fsd, dim3((B * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_points, d_seeds, d_planes,
+                     B, N, P, K, max_radius);
   HIPCHK(hipGetLastError());
   return 0;
 }
