@@ -47,6 +47,9 @@ constexpr int kLsCurv = 2;        // trials granted to a step computed with cons
 constexpr int kCurvFailMax = 2;   // consecutive curvature-step failures before Gauss-Newton is latched
 constexpr int kGroupedMin = 512;    // list length from which the grouped Riccati blocks are used
 constexpr double kAccFeas = 1e-6; // acceptable termination: feasibility / complementarity level
+constexpr int kDenseDiv = 8;      // identity list while more than B / kDenseDiv instances iterate; below: compacted list,
+                                  // and the survivors move to the compact workspace at the host's next look
+constexpr int kMigrateMin = 1024; // batches smaller than this never migrate
 
 enum Status : int { ST_ACTIVE = 100 };
 
@@ -71,6 +74,7 @@ struct Ws {
   int *redo, *force_gn, *gn_sticky, *curv_fail, *usedc, *stall;
   int *active_hist;               // [max_passes] instances still iterating after each pass
   int *act_idx, *n_act;           // compacted list of the instances still iterating, its length
+  int *orig;                      // [Bp] compact workspace only: column -> instance of the caller's batch
 };
 
 #define IDX(slot, k, b) (((size_t)(slot) * W.N + (size_t)(k)) * W.Bp + (size_t)(b))
@@ -126,7 +130,9 @@ __global__ __launch_bounds__(256) void k_init(Ws W, const double *__restrict__ x
 // z (current buffer of each instance) -> z_out[b][k][v]; stats
 __global__ __launch_bounds__(256) void k_unpack(Ws W, double *__restrict__ zout, int *__restrict__ exitflag,
                                                 int *__restrict__ iters, double *__restrict__ kkt,
-                                                double *__restrict__ obj, int B, int nv) {
+                                                double *__restrict__ obj, int B, int nv,
+                                                const int *__restrict__ orig) {
+  // orig != nullptr: W is the compact workspace, column b belongs to instance orig[b] of the batch
   __shared__ double tile[64][65];
   const int N = W.N;
   const int C = N * nv;
@@ -144,17 +150,18 @@ __global__ __launch_bounds__(256) void k_unpack(Ws W, double *__restrict__ zout,
   __syncthreads();
   for (int r = ty; r < 64; r += 4) {
     int b = b0 + r, c = c0 + tx;
-    if (b < B && c < C) zout[(size_t)b * C + c] = tile[tx][r];
+    if (b < B && c < C) zout[(size_t)(orig ? orig[b] : b) * C + c] = tile[tx][r];
   }
   if (blockIdx.y == 0 && threadIdx.x < 64) {
     int b = b0 + threadIdx.x;
     if (b < B) {
+      const int ob = orig ? orig[b] : b;
       int st = W.status[b];
-      exitflag[b] = (st == ST_ACTIVE) ? 0 : st;
-      iters[b] = W.iters[b];
+      exitflag[ob] = (st == ST_ACTIVE) ? 0 : st;
+      iters[ob] = W.iters[b];
       double r = fmax(fmax(W.res_stat[b], W.res_eq[b]), fmax(W.res_ineq[b], W.res_comp[b]));
-      kkt[b] = r;
-      obj[b] = W.obj[b];
+      kkt[ob] = r;
+      obj[ob] = W.obj[b];
     }
   }
 }
@@ -181,13 +188,54 @@ __global__ __launch_bounds__(1024) void k_compact(Ws W, int B, int pass) {
   }
   const int total = sums[1023];
   // while most instances are still iterating the identity list keeps every access coalesced
-  const bool dense = (total * 8 > B);
+  const bool dense = (total * kDenseDiv > B);
   int base = dense ? lo : sums[tid] - cnt;
   for (int b = lo; b < hi; b++)
     if (dense || W.status[b] == ST_ACTIVE) W.act_idx[base++] = b;
   if (tid == 1023) {
     *W.n_act = dense ? B : total;
     W.active_hist[pass] = total;
+  }
+}
+
+// ===========================================================================
+// k_migrate: once few instances are left their whole iteration state moves to the
+// dense columns 0..n-1 of a small second workspace.  Indexing scattered survivors
+// through the list costs a 64-byte sector per 8-byte element (every pass then moves
+// as many bytes as a full batch); one gather of that kind pays for itself in the
+// next pass.  Runs between k_step and the next k_sweep: what crosses that boundary
+// is the current iterate, the step, the parameters and the per-instance words.
+// ===========================================================================
+__global__ __launch_bounds__(64) void k_migrate(const Ws S, const Ws D, int n, int nv, int m, int nx, int npar) {
+  const int li = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+  if (li >= n) return;
+  const int b = S.act_idx[li];
+  const int cur = S.cur[b];
+  auto si = [&](int slot) { return ((size_t)slot * S.N + k) * S.Bp + b; };
+  auto di = [&](int slot) { return ((size_t)slot * D.N + k) * D.Bp + li; };
+  for (int j = 0; j < nv; j++) { D.z[0][di(j)] = S.z[cur][si(j)]; D.dz[di(j)] = S.dz[si(j)]; }
+  for (int i = 0; i < m; i++) {
+    D.t[0][di(i)] = S.t[cur][si(i)];
+    D.lam[0][di(i)] = S.lam[cur][si(i)];
+    D.dtt[di(i)] = S.dtt[si(i)];
+    D.dlam[di(i)] = S.dlam[si(i)];
+  }
+  for (int j = 0; j < nx; j++) { D.nu[0][di(j)] = S.nu[cur][si(j)]; D.nunew[di(j)] = S.nunew[si(j)]; }
+  for (int j = 0; j < npar; j++) D.p[di(j)] = S.p[si(j)];
+  D.gphi[di(0)] = S.gphi[si(0)];
+  if (k == 0) {
+    D.amin_p[li] = S.amin_p[b]; D.amin_d[li] = S.amin_d[b];
+    D.mu[li] = S.mu[b]; D.rho[li] = S.rho[b]; D.phi0[li] = S.phi0[b]; D.Dd[li] = S.Dd[b];
+    D.fcur[li] = S.fcur[b]; D.thcur[li] = S.thcur[b]; D.logcur[li] = S.logcur[b];
+    D.res_stat[li] = S.res_stat[b]; D.res_eq[li] = S.res_eq[b]; D.res_ineq[li] = S.res_ineq[b];
+    D.res_comp[li] = S.res_comp[b]; D.obj[li] = S.obj[b];
+    D.status[li] = S.status[b]; D.iters[li] = S.iters[b]; D.ls[li] = S.ls[b]; D.newstep[li] = S.newstep[b];
+    D.redo[li] = S.redo[b]; D.force_gn[li] = S.force_gn[b]; D.gn_sticky[li] = S.gn_sticky[b];
+    D.curv_fail[li] = S.curv_fail[b]; D.usedc[li] = S.usedc[b]; D.stall[li] = S.stall[b];
+    D.cur[li] = 0;
+    D.orig[li] = b;
+    D.act_idx[li] = li;
+    if (li == 0) *D.n_act = n;
   }
 }
 
@@ -202,7 +250,7 @@ __global__ __launch_bounds__(1024) void k_compact(Ws W, int B, int pass) {
 //     loops; absent entries load row 0 and are masked -- a branch around a load,
 //     even a wave-uniform one, makes hipcc wait for every element separately).
 template <class C>
-__global__ __launch_bounds__(256) void k_sweep(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
+__global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
                                                const int B, const int first) {
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV;
   const DevTables &T = *Tp;
@@ -1469,6 +1517,8 @@ struct rmpc_handle {
   DevTables T;
   DevTables *d_T = nullptr;
   Ws W;
+  Ws Wc;            // compact workspace the last survivors of a batch migrate to (Bpc columns; Bpc == 0: none)
+  int Bpc = 0;
   int device = 0;
   int max_batch = 0;
   int Bp = 0;
@@ -1769,10 +1819,15 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   W.active_hist = c.take<int>(max_passes + 8);
   W.act_idx = c.take<int>(Bp);
   W.n_act = c.take<int>(64);
+  W.orig = c.take<int>(Bp);
   return (c.off + 255) & ~(size_t)255;
 }
 
 static int passes_cap(const DevModel &M) { return 4 * M.max_iter + 64; }
+// columns of the compact workspace (0: batches of this handle never migrate)
+static int compact_columns(int max_batch) {
+  return max_batch >= kMigrateMin ? ((max_batch + kDenseDiv - 1) / kDenseDiv + 63) / 64 * 64 : 0;
+}
 
 // Algorithmic bytes (DESIGN.md, section "Kernels"): what one ACTIVE lane must read and
 // write by design.  Sweep / step lanes are (instance, stage) pairs, riccati lanes are
@@ -1798,26 +1853,35 @@ static void fill_lane_bytes(rmpc_handle *h, int B) {
   h->lane_bytes[K_UNPACK] = 16 * (int64_t)B * M.N * M.nv;
 }
 
+// The workspace the passes currently run in: the batch's own, or the compact one after migration
+// (B = number of columns in use).
+struct Phase {
+  Ws W;
+  int B;
+};
+
 template <class C>
-static void launch_pass(rmpc_handle *h, int B, int first, int pass, hipStream_t st, int which) {
-  const int lanes = h->Bp * h->M.N;
-  if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, h->W, B, first);
+static void launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hipStream_t st, int which) {
+  const int B = ph.B;
+  const int lanes = ph.W.Bp * h->M.N;
+  if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, ph.W, B, first);
   else if (which == K_RICCATI) {
-    hipLaunchKernelGGL((k_riccati<C, C::IPB>), dim3((B + C::IPB - 1) / C::IPB), dim3(64 * C::IPB), 0, st, h->M, h->W, B, first, pass);
+    if (B >= kGroupedMin)
+      hipLaunchKernelGGL((k_riccati<C, C::IPB>), dim3((B + C::IPB - 1) / C::IPB), dim3(64 * C::IPB), 0, st, h->M, ph.W, B, first, pass);
     const int tail_blocks = B < kGroupedMin ? B : kGroupedMin;
-    hipLaunchKernelGGL((k_riccati<C, 1>), dim3(tail_blocks), dim3(64), 0, st, h->M, h->W, B, first, pass);
+    hipLaunchKernelGGL((k_riccati<C, 1>), dim3(tail_blocks), dim3(64), 0, st, h->M, ph.W, B, first, pass);
   }
-  else hipLaunchKernelGGL((k_step<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, h->W, B);
+  else hipLaunchKernelGGL((k_step<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, ph.W, B);
 }
 
-static void launch_variant(rmpc_handle *h, int B, int first, int pass, hipStream_t st, int which) {
+static void launch_variant(rmpc_handle *h, const Phase &ph, int first, int pass, hipStream_t st, int which) {
   switch (h->variant) {
-    case 0: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>(h, B, first, pass, st, which); break;
-    case 1: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 3, 1>>(h, B, first, pass, st, which); break;
-    case 2: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 7, 0>>(h, B, first, pass, st, which); break;
-    case 3: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 7, 1>>(h, B, first, pass, st, which); break;
-    case 4: launch_pass<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>(h, B, first, pass, st, which); break;
-    case 5: launch_pass<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>(h, B, first, pass, st, which); break;
+    case 0: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>(h, ph, first, pass, st, which); break;
+    case 1: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 3, 1>>(h, ph, first, pass, st, which); break;
+    case 2: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 7, 0>>(h, ph, first, pass, st, which); break;
+    case 3: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 7, 1>>(h, ph, first, pass, st, which); break;
+    case 4: launch_pass<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>(h, ph, first, pass, st, which); break;
+    case 5: launch_pass<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>(h, ph, first, pass, st, which); break;
   }
 }
 
@@ -1875,24 +1939,40 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
   }
   const int cap = max_passes_override > 0 ? max_passes_override : h->max_passes;
   int pass = 0, next_check = 8;
+  Phase ph{h->W, B};
+  bool migrated = false;
+  const bool may_migrate = h->Bpc > 0 && B >= kMigrateMin && !getenv("RMPC_NO_MIGRATE");
   for (; pass < cap; pass++) {
     const int first = pass == 0;
-    { ProfScope ps(h, st, K_SWEEP); launch_variant(h, B, first, pass, st, K_SWEEP); }
-    { ProfScope ps(h, st, K_RICCATI); launch_variant(h, B, first, pass, st, K_RICCATI); }
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, h->W, B, pass);
-    { ProfScope ps(h, st, K_STEP); launch_variant(h, B, first, pass, st, K_STEP); }
+    { ProfScope ps(h, st, K_SWEEP); launch_variant(h, ph, first, pass, st, K_SWEEP); }
+    { ProfScope ps(h, st, K_RICCATI); launch_variant(h, ph, first, pass, st, K_RICCATI); }
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, ph.W, ph.B, pass);
+    { ProfScope ps(h, st, K_STEP); launch_variant(h, ph, first, pass, st, K_STEP); }
     if (pass + 1 == next_check && max_passes_override <= 0) {
       HIPCHK(hipMemcpyAsync(h->h_active, h->W.active_hist + pass, sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      if (*h->h_active == 0) { pass++; break; }
-      next_check += 4;
+      const int n = *h->h_active;
+      if (n == 0) { pass++; break; }
+      if (may_migrate && !migrated && n * kDenseDiv <= B) {
+        // k_compact has just left the compacted list of the n survivors in the batch's workspace
+        hipLaunchKernelGGL(k_migrate, dim3((n + 63) / 64, M.N), dim3(64), 0, st, h->W, h->Wc, n, M.nv, M.m, M.nx, M.npar);
+        ph = Phase{h->Wc, n};
+        migrated = true;
+      }
+      next_check += (may_migrate && !migrated) ? 2 : 4;  // look more often while the migration is still ahead
     }
   }
   h->last_passes = pass;
   {
     ProfScope ps(h, st, K_UNPACK);
     dim3 g((B + 63) / 64, (M.N * M.nv + 63) / 64);
-    hipLaunchKernelGGL(k_unpack, g, dim3(256), 0, st, h->W, d_zout, d_exit, d_iters, d_kkt, d_obj, B, M.nv);
+    hipLaunchKernelGGL(k_unpack, g, dim3(256), 0, st, h->W, d_zout, d_exit, d_iters, d_kkt, d_obj, B, M.nv, (const int *)nullptr);
+    if (migrated) {
+      // the survivors' results overwrite the stale rows the first launch wrote for them
+      dim3 gc((ph.B + 63) / 64, (M.N * M.nv + 63) / 64);
+      hipLaunchKernelGGL(k_unpack, gc, dim3(256), 0, st, h->Wc, d_zout, d_exit, d_iters, d_kkt, d_obj, ph.B, M.nv,
+                         (const int *)h->Wc.orig);
+    }
   }
   HIPCHK(hipGetLastError());
   if (h->profiling) {
@@ -1902,6 +1982,11 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
     HIPCHK(hipMemcpyAsync(h->h_hist.data(), h->W.active_hist, sizeof(int) * pass, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     prof_collect(h);
+    if (getenv("RMPC_DUMP_HIST")) {  // development aid: instances still iterating after each pass
+      fprintf(stderr, "rmpc active after pass:");
+      for (int p = 0; p < pass; p++) fprintf(stderr, " %d", h->h_hist[p]);
+      fprintf(stderr, "\n");
+    }
     double act_in = 0, act_out = 0;
     for (int p = 0; p < pass; p++) {
       act_in += (p == 0) ? B : h->h_hist[p - 1];
@@ -1932,7 +2017,8 @@ int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch) {
   if (build_tables(*desc, M, T, err) != 0) { g_err = err; return -1; }
   Ws W;
   const int Bp = (max_batch + 63) / 64 * 64;
-  return (int64_t)carve(M, Bp, passes_cap(M), nullptr, W);
+  const int Bpc = compact_columns(max_batch);
+  return (int64_t)(carve(M, Bp, passes_cap(M), nullptr, W) + (Bpc ? carve(M, Bpc, 0, nullptr, W) : 0));
 }
 
 int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
@@ -1956,11 +2042,17 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   hipError_t e = hipSetDevice(h->device);
   if (e != hipSuccess) { delete h; return fail(std::string("hipSetDevice: ") + hipGetErrorString(e)); }
   Ws tmp;
-  h->ws_bytes = carve(h->M, h->Bp, h->max_passes, nullptr, tmp);
+  h->Bpc = compact_columns(max_batch);
+  const size_t big = carve(h->M, h->Bp, h->max_passes, nullptr, tmp);
+  h->ws_bytes = big + (h->Bpc ? carve(h->M, h->Bpc, 0, nullptr, tmp) : 0);
   e = hipMalloc(&h->ws_base, h->ws_bytes);
   if (e != hipSuccess) { delete h; return fail(std::string("hipMalloc workspace: ") + hipGetErrorString(e)); }
   (void)hipMemset(h->ws_base, 0, h->ws_bytes);
   carve(h->M, h->Bp, h->max_passes, h->ws_base, h->W);
+  if (h->Bpc) {
+    carve(h->M, h->Bpc, 0, (char *)h->ws_base + big, h->Wc);
+    h->Wc.active_hist = h->W.active_hist;  // one history per batch, whichever workspace the pass ran in
+  }
   e = hipMalloc((void **)&h->d_T, sizeof(DevTables));
   if (e == hipSuccess) e = hipMemcpy(h->d_T, &h->T, sizeof(DevTables), hipMemcpyHostToDevice);
   if (e != hipSuccess) { (void)hipFree(h->ws_base); delete h; return fail(std::string("row tables: ") + hipGetErrorString(e)); }
@@ -2142,7 +2234,7 @@ int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x
   dim3 g2((B + 63) / 64, (M.N * M.nv + 63) / 64);
   hipLaunchKernelGGL(k_pack, g2, dim3(256), 0, st, h->d_x0, h->W.z[0], B, M.N * M.nv, M.nv, M.N, h->Bp);
   hipLaunchKernelGGL(k_init, dim3((B + 255) / 256), dim3(256), 0, st, h->W, h->d_xinit, B, M.nx, M.mu0);
-  launch_variant(h, B, 1, 0, st, K_SWEEP);
+  launch_variant(h, Phase{h->W, B}, 1, 0, st, K_SWEEP);
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
   // gather SoA -> instance-major on the host (debug path, not timed)

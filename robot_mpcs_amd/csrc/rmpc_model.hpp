@@ -107,6 +107,9 @@ struct Cfg {
   static constexpr bool CURV = (ROBOT_ == RMPC_ROBOT_CHAIN) && (NS_ == 0) && (NQ_ <= 3);
   // instances (wavefronts) per block of the Riccati kernel: neighbours share cache lines
   static constexpr int IPB = (NX > 8) ? 8 : 16;
+  // k_sweep register budget: two wavefronts per SIMD (256 VGPRs) for the three-joint robots -- a
+  // few spilled doubles cost less than half the latency hiding; the arm needs the whole file
+  static constexpr int SWEEP_WPE = (NQ > 3) ? 1 : 2;
 };
 
 // ---------------------------------------------------------------------------

@@ -56,6 +56,27 @@ def test_solve_matches_oracle(rt, name, B, seed):
     np.testing.assert_allclose(gpu["obj"], cpu["obj"], rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("name,B,seed", [("cfg2", 2048, 7), ("cfg3", 1280, 8)])
+def test_survivor_migration_is_transparent(rt, name, B, seed):
+    """Batches of >= 1024 instances move their last survivors to the compact workspace
+    (k_migrate).  Same arithmetic in other columns: results must be bit-identical to a solve with
+    migration switched off, and match the oracle like any other batch."""
+    sc = rt["make_scenario"](name, B=B, seed=seed)
+    s = rt["Solver"](sc.desc, max_batch=B)
+    gpu = s.solve(sc.xinit, sc.x0, sc.params)
+    os.environ["RMPC_NO_MIGRATE"] = "1"
+    try:
+        ref = s.solve(sc.xinit, sc.x0, sc.params)
+    finally:
+        del os.environ["RMPC_NO_MIGRATE"]
+    s.close()
+    for key in ("z", "exitflag", "iters", "obj", "kkt"):
+        assert np.array_equal(gpu[key], ref[key]), key
+    assert gpu["iters"].max() > 16   # some instances did outlive the migration point
+    cpu = rt["Oracle"](sc.desc).solve_batch(sc.xinit, sc.x0, sc.params)
+    _check_plan(gpu, cpu, sc.desc["nx"] + sc.desc["ns"])
+
+
 @pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "boxer", "pointRobot"])
 def test_solve_matches_golden_vectors(rt, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
