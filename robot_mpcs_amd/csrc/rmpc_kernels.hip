@@ -60,8 +60,9 @@ struct Ws {
   int N, Bp;
   double *p;                      // [npar][N][Bp]
   double *z[2], *t[2], *lam[2], *nu[2];
-  double *dz, *dtt, *dlam, *nunew;
-  double *Qqq, *Cqq, *Dg, *cs, *q0, *q1, *gfa, *grow, *Jq, *rc, *A5, *B5;
+  double *dz, *nunew;
+  double *grow[2], *Jq[2];        // row values / FK-row gradients at the iterate of the same buffer index
+  double *Qqq, *Cqq, *Dg, *cs, *q0, *q1, *gfa, *rc, *A5, *B5;
   double *Kg, *kff, *Pst;        // gains, cost-to-go (upper triangle of P, then p)
   double *zeros;                 // [N][Bp] zero-filled, never written (source of structural zeros)
   double *part;                   // [P_COUNT][N][Bp]
@@ -206,7 +207,8 @@ __global__ __launch_bounds__(1024) void k_compact(Ws W, int B, int pass) {
 // next pass.  Runs between k_step and the next k_sweep: what crosses that boundary
 // is the current iterate, the step, the parameters and the per-instance words.
 // ===========================================================================
-__global__ __launch_bounds__(64) void k_migrate(const Ws S, const Ws D, int n, int nv, int m, int nx, int npar) {
+__global__ __launch_bounds__(64) void k_migrate(const Ws S, const Ws D, int n, int nv, int m, int nx, int npar, int nh,
+                                                int njq) {
   const int li = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
   if (li >= n) return;
   const int b = S.act_idx[li];
@@ -217,9 +219,9 @@ __global__ __launch_bounds__(64) void k_migrate(const Ws S, const Ws D, int n, i
   for (int i = 0; i < m; i++) {
     D.t[0][di(i)] = S.t[cur][si(i)];
     D.lam[0][di(i)] = S.lam[cur][si(i)];
-    D.dtt[di(i)] = S.dtt[si(i)];
-    D.dlam[di(i)] = S.dlam[si(i)];
   }
+  for (int i = 0; i < nh; i++) D.grow[0][di(i)] = S.grow[cur][si(i)];
+  for (int i = 0; i < njq; i++) D.Jq[0][di(i)] = S.Jq[cur][si(i)];
   for (int j = 0; j < nx; j++) { D.nu[0][di(j)] = S.nu[cur][si(j)]; D.nunew[di(j)] = S.nunew[si(j)]; }
   for (int j = 0; j < npar; j++) D.p[di(j)] = S.p[si(j)];
   D.gphi[di(0)] = S.gphi[si(0)];
@@ -272,8 +274,10 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
   double *__restrict__ nn = W.nu[nxt];
   const double *__restrict__ pp = W.p;
   const double *__restrict__ dzp = W.dz;
-  const double *__restrict__ dtp = W.dtt;
-  const double *__restrict__ dlp = W.dlam;
+  const double *__restrict__ gro = W.grow[cur];   // row values and FK-row gradients at the current iterate:
+  const double *__restrict__ jqo = W.Jq[cur];     //  the slack / multiplier steps are recomputed from them
+  double *__restrict__ grn = W.grow[nxt];
+  double *__restrict__ jqn = W.Jq[nxt];
   const double *__restrict__ nup = W.nunew;
   const double mu = W.mu[b];
 
@@ -287,12 +291,12 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
     adual = __longlong_as_double((long long)W.amin_d[b]);
   }
   const double am = nostep ? 0.0 : alpha;   // multiplies the steps (0 on first / null passes:
-  const double dm = nostep ? 0.0 : adual;   //  the step arrays are zero-filled or stale but finite)
+  const double dm = nostep ? 0.0 : adual;   //  the steps are stale but finite)
 
   // ---- trial stage vector, costates, next stage's state ------------------------
   double z[NV], xk1[NX], nuk[NX], nun[NX];
+  double zo[NV], dzo[NV];   // current iterate and step of this stage (the row steps are recomputed from them)
   {
-    double zo[NV], dzo[NV];
 #pragma unroll
     for (int j = 0; j < NV; j++) { zo[j] = zc[IDX(j, k, b)]; dzo[j] = dzp[IDX(j, k, b)]; }
     const int k1 = k < N - 1 ? k + 1 : k;  // clamped: loads stay unconditional
@@ -359,12 +363,16 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
 
   // trial slack / multiplier of row i and their bookkeeping; returns sigma, ca, cb, lv
   struct RowW { double sig, ca, cb, lv; };
-  auto row_core = [&](int i, double g, double tcv, double lcv, double dtv, double dlv) __attribute__((always_inline)) -> RowW {
+  // (gold, gdz: row value at the current iterate and J_i dz -- the slack / multiplier steps of the row are
+  //  recomputed with the very expressions k_step took its step lengths from)
+  auto row_core = [&](int i, double g, double tcv, double lcv, double gold, double gdz) __attribute__((always_inline)) -> RowW {
     double tv, lv;
     if (first) {
       tv = g > kTMin ? g : kTMin;
       lv = mu / tv;
     } else {
+      const double dtv = gdz + (gold - tcv);
+      const double dlv = (mu - tcv * lcv - lcv * dtv) / tcv;
       tv = tcv + am * dtv;
       lv = lcv + dm * dlv;
     }
@@ -411,7 +419,17 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
     for (int r = T.slot_row_begin[SL]; r < T.slot_row_begin[SL + 1]; r++) {
       const int i = T.fk_row[r], kind = T.fk_kind[r], ob = T.fk_obst[r], mi = T.fk_mod[r];
       // requests first, arithmetic after
-      const double tcv = tc[IDX(i, k, b)], lcv = lc[IDX(i, k, b)], dtv = dtp[IDX(i, k, b)], dlv = dlp[IDX(i, k, b)];
+      const int fi = T.fk_idx[r];
+      const double tcv = tc[IDX(i, k, b)], lcv = lc[IDX(i, k, b)], gold = gro[IDX(i, k, b)];
+      double gdz = 0.0;
+      {
+        double jo[NQ];
+#pragma unroll
+        for (int a = 0; a < NQ; a++) jo[a] = jqo[IDX(fi * NQ + a, k, b)];
+#pragma unroll
+        for (int a = 0; a < NQ; a++) gdz += jo[a] * dzo[a];
+        if constexpr (NS > 0) gdz += dzo[NX];
+      }
       double gq[NQ];
       double h, cinv = 0.0;
       if (kind == ROW_RADIAL) {
@@ -469,11 +487,10 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
       }
       double g = h;
       if constexpr (NS > 0) g += sl;  // softened rows (intended InequalityManager.py:29-32)
-      W.grow[IDX(i, k, b)] = g;
-      const int fi = T.fk_idx[r];
+      grn[IDX(i, k, b)] = g;
 #pragma unroll
-      for (int a = 0; a < NQ; a++) W.Jq[IDX(fi * NQ + a, k, b)] = gq[a];
-      const RowW rw = row_core(i, g, tcv, lcv, dtv, dlv);
+      for (int a = 0; a < NQ; a++) jqn[IDX(fi * NQ + a, k, b)] = gq[a];
+      const RowW rw = row_core(i, g, tcv, lcv, gold, gdz);
 #pragma unroll
       for (int a = 0; a < NQ; a++) {
         q0[a] += gq[a] * rw.ca;
@@ -511,7 +528,7 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
 #pragma unroll
   for (int j = 0; j < NV; j++) {
     // unconditional, clamped requests for the (up to) four rows of variable j
-    double tcv[kVarRows], lcv[kVarRows], dtv[kVarRows], dlv[kVarRows], lim[kVarRows];
+    double tcv[kVarRows], lcv[kVarRows], lim[kVarRows];
 #pragma unroll
     for (int u = 0; u < kVarRows; u++) {
       const int i = T.v_row[j][u];
@@ -519,8 +536,6 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
       const int po = T.v_poff[j][u];
       tcv[u] = tc[IDX(ii, k, b)];
       lcv[u] = lc[IDX(ii, k, b)];
-      dtv[u] = dtp[IDX(ii, k, b)];
-      dlv[u] = dlp[IDX(ii, k, b)];
       const double pl = pp[IDX(po >= 0 ? po : 0, k, b)];
       lim[u] = po >= 0 ? pl : T.v_val[j][u];
     }
@@ -546,8 +561,12 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
       }
       double g = h;
       if constexpr (NS > 0) { if (soft) g += sl; }
-      if (T.v_poff[j][u] >= 0) W.grow[IDX(i, k, b)] = g;  // general rows keep their value for k_step
-      const RowW rw = row_core(i, g, tcv[u], lcv[u], dtv[u], dlv[u]);
+      if (T.v_poff[j][u] >= 0) grn[IDX(i, k, b)] = g;  // general rows keep their value for k_step
+      // the same row at the current iterate (what k_step read back or recomputed)
+      double gold = neutral ? 1.0 : sg * (zo[j] - lim[u]);
+      double gdz = sg * dzo[j];
+      if constexpr (NS > 0) { if (soft) { gold += zo[NX]; gdz += dzo[NX]; } }
+      const RowW rw = row_core(i, g, tcv[u], lcv[u], gold, gdz);
       if (neutral) continue;
       q0[j] += sg * rw.ca;
       q1[j] += sg * rw.cb;
@@ -728,7 +747,7 @@ __device__ __forceinline__ double wave_min(double v) {
 }
 
 template <class C, int IPB>
-__global__ __launch_bounds__(64 * IPB) void k_riccati(const DevModel M, const Ws W, const int B, const int first,
+__global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel M, const Ws W, const int B, const int first,
                                                 const int pass) {
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV, NW = C::NW;
   constexpr bool DD = (C::ROBOT == RMPC_ROBOT_DIFFDRIVE);
@@ -1263,10 +1282,8 @@ __global__ __launch_bounds__(256) void k_step(const DevModel M, const DevTables 
   const double *__restrict__ zc = W.z[cur];
   const double *__restrict__ tc = W.t[cur];
   const double *__restrict__ lc = W.lam[cur];
-  const double *__restrict__ grow = W.grow;
-  const double *__restrict__ Jq = W.Jq;
-  double *__restrict__ dto = W.dtt;
-  double *__restrict__ dlo = W.dlam;
+  const double *__restrict__ grow = W.grow[cur];
+  const double *__restrict__ Jq = W.Jq[cur];
   const double mu = W.mu[b];
   double dz[NV], z[NV], gfv[NV];
 #pragma unroll
@@ -1282,8 +1299,7 @@ __global__ __launch_bounds__(256) void k_step(const DevModel M, const DevTables 
   auto row = [&](int i, double gdz, double g, double tv, double lv) __attribute__((always_inline)) {
     const double dt = gdz + (g - tv);
     const double dl = (mu - tv * lv - lv * dt) / tv;
-    dto[IDX(i, k, b)] = dt;
-    dlo[IDX(i, k, b)] = dl;
+    (void)i;  // the steps themselves are not stored: k_sweep recomputes them from the same inputs
     if (dt < 0) ap = fmin(ap, -kTau * tv / dt);
     if (dl < 0) ad = fmin(ad, -kTau * lv / dl);
     gphi -= mu * dt / tv;
@@ -1788,8 +1804,6 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
     W.nu[i] = c.take<double>(S * M.nx);
   }
   W.dz = c.take<double>(S * M.nv);
-  W.dtt = c.take<double>(S * M.m);
-  W.dlam = c.take<double>(S * M.m);
   W.nunew = c.take<double>(S * M.nx);
   W.Qqq = c.take<double>(S * nq2);
   W.Cqq = c.take<double>(S * nq2);
@@ -1798,8 +1812,10 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   W.q0 = c.take<double>(S * M.nv);
   W.q1 = c.take<double>(S * M.nv);
   W.gfa = c.take<double>(S * M.nv);
-  W.grow = c.take<double>(S * (M.nh > 0 ? M.nh : 1));
-  W.Jq = c.take<double>(S * (M.nfk > 0 ? M.nfk * nq : 1));
+  for (int i = 0; i < 2; i++) {
+    W.grow[i] = c.take<double>(S * (M.nh > 0 ? M.nh : 1));
+    W.Jq[i] = c.take<double>(S * (M.nfk > 0 ? M.nfk * nq : 1));
+  }
   W.rc = c.take<double>(S * M.nx);
   W.A5 = c.take<double>(S * 25);
   W.B5 = c.take<double>(S * 10);
@@ -1836,7 +1852,7 @@ static void fill_lane_bytes(rmpc_handle *h, int B) {
   const DevModel &M = h->M;
   const int nq2 = M.n * (M.n + 1) / 2;
   const int64_t dd = (M.robot == RMPC_ROBOT_DIFFDRIVE) ? 35 : 0;
-  const int64_t sweep_rd = M.nv * 2 + M.m * 4 + M.nx * 4 + M.npar + M.nx * 2 + 2;
+  const int64_t sweep_rd = M.nv * 2 + M.m * 2 + M.nfk * (1 + M.n) + M.nx * 4 + M.npar + M.nx * 2 + 2;
   const int64_t sweep_wr = M.nv + 2 * M.m + M.nx + nq2 + (M.use_curv ? nq2 : 0) + (M.nv - M.n) + (M.ns ? M.nv : 0) +
                            3 * M.nv + M.nh + M.nfk * M.n + M.nx + dd + P_COUNT;
   const int64_t np2 = M.nx * (M.nx + 1) / 2 + M.nx;
@@ -1845,7 +1861,7 @@ static void fill_lane_bytes(rmpc_handle *h, int B) {
                          (M.nw * M.nx + M.nw) + np2;
   const int64_t ric_wr = (M.nw * M.nx + M.nw) + np2 + M.nv + M.nx;
   const int64_t step_rd = 3 * M.nv + 2 * M.m + M.nh + M.nfk * M.n;
-  const int64_t step_wr = 2 * M.m + 3;  // two of the three are atomic minima
+  const int64_t step_wr = 3;  // gphi and two atomic minima (the row steps are recomputed by k_sweep, not stored)
   h->lane_bytes[K_PACK] = 16 * ((int64_t)B * (M.nx + (int64_t)M.N * (M.nv + M.npar)));
   h->lane_bytes[K_SWEEP] = 8 * (sweep_rd + sweep_wr);
   h->lane_bytes[K_RICCATI] = 8 * (int64_t)M.N * (ric_rd + ric_wr);
@@ -1955,7 +1971,8 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
       if (n == 0) { pass++; break; }
       if (may_migrate && !migrated && n * kDenseDiv <= B) {
         // k_compact has just left the compacted list of the n survivors in the batch's workspace
-        hipLaunchKernelGGL(k_migrate, dim3((n + 63) / 64, M.N), dim3(64), 0, st, h->W, h->Wc, n, M.nv, M.m, M.nx, M.npar);
+        hipLaunchKernelGGL(k_migrate, dim3((n + 63) / 64, M.N), dim3(64), 0, st, h->W, h->Wc, n, M.nv, M.m, M.nx, M.npar,
+                           M.nh, M.nfk * M.n);
         ph = Phase{h->Wc, n};
         migrated = true;
       }
@@ -2247,7 +2264,7 @@ int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x
   std::vector<double> Qqq, Dg, cs, q0, q1, rc, gr, part;
   const int nq = M.n, nq2 = nq * (nq + 1) / 2, nv = M.nv;
   if (fetch(h->W.Qqq, nq2, Qqq) || fetch(h->W.Dg, nv - nq, Dg) || fetch(h->W.cs, nv, cs) || fetch(h->W.q0, nv, q0) ||
-      fetch(h->W.q1, nv, q1) || fetch(h->W.rc, M.nx, rc) || fetch(h->W.grow, M.nh > 0 ? M.nh : 1, gr) ||
+      fetch(h->W.q1, nv, q1) || fetch(h->W.rc, M.nx, rc) || fetch(h->W.grow[1], M.nh > 0 ? M.nh : 1, gr)  /* first pass: cur = 0, written to buffer 1 */ ||
       fetch(h->W.part, P_COUNT, part))
     return -1;
   auto at = [&](const std::vector<double> &v, int slot, int k, int b) { return v[((size_t)slot * M.N + k) * h->Bp + b]; };

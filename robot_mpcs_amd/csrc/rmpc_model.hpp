@@ -110,6 +110,9 @@ struct Cfg {
   // k_sweep register budget: two wavefronts per SIMD (256 VGPRs) for the three-joint robots -- a
   // few spilled doubles cost less than half the latency hiding; the arm needs the whole file
   static constexpr int SWEEP_WPE = (NQ > 3) ? 1 : 2;
+  // k_riccati: no register cap -- at 96 VGPRs (five wavefronts per SIMD) the recursion spills inside its
+  // stage loop and runs 30 % slower (measured, cfg2)
+  static constexpr int RIC_WPE = 1;
 };
 
 // ---------------------------------------------------------------------------
