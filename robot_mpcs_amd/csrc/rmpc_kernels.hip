@@ -62,8 +62,12 @@ struct Ws {
   double *z[2], *t[2], *lam[2], *nu[2];
   double *dz, *nunew;
   double *grow[2], *Jq[2];        // row values / FK-row gradients at the iterate of the same buffer index
-  double *Qqq, *Cqq, *Dg, *cs, *q0, *q1, *gfa, *rc, *A5, *B5;
-  double *Kg, *kff, *Pst;        // gains, cost-to-go (upper triangle of P, then p)
+  double *R;                      // [Bp][N][rs] stage records k_sweep -> k_riccati (layout: Cfg::R_*)
+  int rs;
+  double *gfa;
+  double *KP;                     // [Bp][N][kps] per instance and stage: gains K | kff | cost-to-go P (dense) | p --
+                                  // private to k_riccati, instance-major so that a wavefront moves a record in one request
+  int kps;                        // record stride (doubles, multiple of 8)
   double *zeros;                 // [N][Bp] zero-filled, never written (source of structural zeros)
   double *part;                   // [P_COUNT][N][Bp]
   double *gphi;                   // [N][Bp]
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
   double *__restrict__ jqn = W.Jq[nxt];
   const double *__restrict__ nup = W.nunew;
   const double mu = W.mu[b];
+  double *__restrict__ rec = W.R + ((size_t)b * N + k) * W.rs;   // this lane's stage record
 
   // ---- step lengths of this trial --------------------------------------
   // null pass: the current point is re-evaluated unchanged so that the step can be
@@ -606,9 +611,9 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
       diffdrive_step<C>(M.dt, z, xn, A5, B5, true);
       constexpr int map[5] = {0, 1, 2, 6, 7};
 #pragma unroll
-      for (int i = 0; i < 25; i++) W.A5[IDX(i, k, b)] = A5[i];
+      for (int i = 0; i < 25; i++) rec[C::R_A5 + i] = A5[i];
 #pragma unroll
-      for (int i = 0; i < 10; i++) W.B5[IDX(i, k, b)] = B5[i];
+      for (int i = 0; i < 10; i++) rec[C::R_B5 + i] = B5[i];
       // A = I outside the reduced block
 #pragma unroll
       for (int j = 3; j < 6; j++) rs[j] += nun[j];
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
 #pragma unroll
     for (int j = 0; j < NX; j++) {
       const double r = xn[j] - xk1[j];
-      W.rc[IDX(j, k, b)] = r;
+      rec[C::R_RC + j] = r;
       req = fmax(req, fabs(r));
       theta += fabs(r);
     }
@@ -652,29 +657,29 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
 #pragma unroll
     for (int a = 0; a < NQ; a++)
 #pragma unroll
-      for (int c = a; c < NQ; c++) W.Qqq[IDX(s++, k, b)] = Qqq[a][c];
+      for (int c = a; c < NQ; c++) rec[C::R_Q + s++] = Qqq[a][c];
   }
-  if constexpr (C::CURV) {
-    if (M.use_curv) {
-      int s = 0;
+  {
+    // (zero when the model or this solve does not use the curvature terms: k_riccati reads the slot regardless)
+    int s = 0;
 #pragma unroll
-      for (int a = 0; a < NQ; a++)
+    for (int a = 0; a < NQ; a++)
 #pragma unroll
-        for (int c = a; c < NQ; c++) W.Cqq[IDX(s++, k, b)] = Cqq[a][c];
-    }
+      for (int c = a; c < NQ; c++) rec[C::R_C + s++] = (C::CURV && M.use_curv) ? Cqq[C::CURV ? a : 0][C::CURV ? c : 0] : 0.0;
   }
 #pragma unroll
-  for (int j = NQ; j < NV; j++) W.Dg[IDX(j - NQ, k, b)] = Dg[j];
+  for (int j = NQ; j < NV; j++) rec[C::R_DG + j - NQ] = Dg[j];
   if constexpr (NS > 0) {
 #pragma unroll
-    for (int j = 0; j < NV; j++) W.cs[IDX(j, k, b)] = cs[j];
+    for (int j = 0; j < NV; j++) rec[C::R_CS + j] = cs[j];
   }
 #pragma unroll
   for (int j = 0; j < NV; j++) {
-    W.q0[IDX(j, k, b)] = gf[j] + q0[j];
-    W.q1[IDX(j, k, b)] = q1[j];
+    rec[C::R_Q0 + j] = gf[j] + q0[j];
+    rec[C::R_Q1 + j] = q1[j];
     W.gfa[IDX(j, k, b)] = gf[j];
   }
+  rec[C::R_ZERO] = 0.0;
   if (!isfinite(f) || !isfinite(theta) || !isfinite(logsum)) bad = 1;
   W.part[IDX(P_F, k, b)] = f;
   W.part[IDX(P_TH, k, b)] = theta;
@@ -751,7 +756,6 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
                                                 const int pass) {
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV, NW = C::NW;
   constexpr bool DD = (C::ROBOT == RMPC_ROBOT_DIFFDRIVE);
-  constexpr int NP2 = NX * (NX + 1) / 2;
   // IPB wavefronts per block work on IPB consecutive list entries: neighbouring instances share
   // the 128-byte lines of the batch-minor arrays, so most of a wave's requests hit the CU's L1
   // Two instantiations are launched every pass and pick their regime from the list length:
@@ -928,11 +932,13 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
       sAB[e] = v;
     }
   };
-  // Loop-invariant source of every LDS entry this lane fills: a pointer into the workspace
-  // (stage 0 of the right slot, or a zero-filled array) plus a constant.  The per-stage fetch is
-  // then an unconditional load per entry -- no branch around any load.
-  const double *const zer = W.zeros + b;
-  const size_t sstr = (size_t)W.Bp;  // stage stride
+  // Loop-invariant source of every LDS entry this lane fills: a pointer into the instance's stage
+  // records (stage 0; an entry of the record, or its zero slot) plus a constant.  The per-stage fetch
+  // is then an unconditional load per entry -- no branch around any load -- and all lanes of the
+  // wavefront address the same few cache lines.
+  const double *const rb = W.R + (size_t)b * N * C::RS;   // stage 0 record of this instance
+  const double *const zer = rb + C::R_ZERO;
+  constexpr size_t sstr = (size_t)C::RS;                  // stage stride of the records
   constexpr int EPL = (NV * NV + 63) / 64;   // stage Hessian entries per lane
   constexpr int TPL = (NX * NV + 63) / 64;   // entries of T = P [A|B] (and of [A|B]) per lane
   constexpr int PPL = (NX * NX + 63) / 64;   // entries of P per lane
@@ -946,20 +952,20 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       if (hi < NQ) {
         const int s = lo * NQ - lo * (lo - 1) / 2 + (hi - lo);
-        qp[u] = W.Qqq + IDX(s, 0, b);
-        if constexpr (C::CURV) cp[u] = W.Cqq + IDX(s, 0, b);
+        qp[u] = rb + C::R_Q + s;
+        if constexpr (C::CURV) cp[u] = rb + C::R_C + s;
       } else if (lo == hi) {
-        qp[u] = W.Dg + IDX(lo - NQ, 0, b);
+        qp[u] = rb + C::R_DG + (lo - NQ);
       } else if (NS > 0 && lo == NX) {
-        qp[u] = W.cs + IDX(hi, 0, b);
+        qp[u] = rb + C::R_CS + hi;
       } else if (NS > 0 && hi == NX) {
-        qp[u] = W.cs + IDX(lo, 0, b);
+        qp[u] = rb + C::R_CS + lo;
       }
     }
   }
-  const double *q0p = lane < NV ? W.q0 + IDX(lane, 0, b) : zer;
-  const double *q1p = lane < NV ? W.q1 + IDX(lane, 0, b) : zer;
-  const double *rcp = lane < NX ? W.rc + IDX(lane, 0, b) : zer;
+  const double *q0p = lane < NV ? rb + C::R_Q0 + lane : zer;
+  const double *q1p = lane < NV ? rb + C::R_Q1 + lane : zer;
+  const double *rcp = lane < NX ? rb + C::R_RC + lane : zer;
   // [A|B] of the diff-drive model: identity outside the reduced (x, y, theta, v, omega) block
   const double *abp[DD ? TPL : 1];
   double abc[DD ? TPL : 1];
@@ -973,10 +979,10 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
         const int ri = (i < 3) ? i : (i >= 6 ? i - 3 : -1);
         if (j < NX) {
           const int rj = (j < 3) ? j : (j >= 6 ? j - 3 : -1);
-          if (ri >= 0 && rj >= 0) abp[u] = W.A5 + IDX(ri * 5 + rj, 0, b);
+          if (ri >= 0 && rj >= 0) abp[u] = rb + C::R_A5 + (ri * 5 + rj);
           else abc[u] = (i == j) ? 1.0 : 0.0;
         } else if (j >= NX + NS && ri >= 0) {
-          abp[u] = W.B5 + IDX(ri * 2 + (j - NX - NS), 0, b);
+          abp[u] = rb + C::R_B5 + (ri * 2 + (j - NX - NS));
         }
       }
     }
@@ -1008,6 +1014,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   };
   fetch_stage(N - 1);
   for (int k = N - 1; k >= 0; k--) {
+    double *const kpr = W.KP + ((size_t)b * N + k) * W.kps;   // this stage's gain / cost-to-go record
     // -- fill ------------------------------------------------------------------------------
 #pragma unroll
     for (int u = 0; u < EPL; u++) {
@@ -1132,10 +1139,10 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
       chol_solve<NW>(L, invd, col);
       if (lane < NX) {
 #pragma unroll
-        for (int i = 0; i < NW; i++) { sK[i * NX + lane] = col[i]; W.Kg[IDX(i * NX + lane, k, b)] = col[i]; }
+        for (int i = 0; i < NW; i++) { sK[i * NX + lane] = col[i]; kpr[i * NX + lane] = col[i]; }
       } else {
 #pragma unroll
-        for (int i = 0; i < NW; i++) { skf[i] = col[i]; W.kff[IDX(i, k, b)] = col[i]; }
+        for (int i = 0; i < NW; i++) { skf[i] = col[i]; kpr[NW * NX + i] = col[i]; }
       }
     }
     WSYNC();
@@ -1168,11 +1175,10 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
       const int e = lane + 64 * u;
       if (e < NX * NX) {
         sP[e] = pn[u];
-        const int i = e / NX, j = e - i * NX;
-        if (i <= j) W.Pst[IDX(i * NX - i * (i - 1) / 2 + (j - i), k, b)] = pn[u];
+        kpr[NW * NX + NW + e] = pn[u];
       }
     }
-    if (lane < NX) { sp[lane] = pnv; W.Pst[IDX(NP2 + lane, k, b)] = pnv; }
+    if (lane < NX) { sp[lane] = pnv; kpr[NW * NX + NW + NX * NX + lane] = pnv; }
     // (the fill of the next stage touches sQ / sq / src only; its barrier orders the sP writes)
   }
   if (!chol_ok) {
@@ -1194,24 +1200,19 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   if (lane < NX) sdx[lane] = 0.0;
   constexpr int FPL = (NW * NX + NW + NX * NX + NX + NX + 63) / 64;
   double fv[FPL];
-  const double *fp[FPL];
+  const double *fp[FPL];   // running pointers: record entries advance by the record stride, rc by the stage stride
+  size_t fst[FPL];
+  constexpr int KPW = NW * NX + NW + NX * NX + NX;
 #pragma unroll
   for (int u = 0; u < FPL; u++) {
-    int e = lane + 64 * u;
-    fp[u] = zer;
-    if (e < NW * NX) fp[u] = W.Kg + IDX(e, 0, b);
-    else if ((e -= NW * NX) < NW) fp[u] = W.kff + IDX(e, 0, b);
-    else if ((e -= NW) < NX * NX) {
-      const int i = e / NX, j = e - i * NX;
-      const int lo = i < j ? i : j, hi = i < j ? j : i;
-      fp[u] = W.Pst + IDX(lo * NX - lo * (lo - 1) / 2 + (hi - lo), 0, b);
-    } else if ((e -= NX * NX) < NX) fp[u] = W.Pst + IDX(NP2 + e, 0, b);
-    else if ((e -= NX) < NX) fp[u] = W.rc + IDX(e, 0, b);
+    const int e = lane + 64 * u;
+    fp[u] = zer; fst[u] = sstr;
+    if (e < KPW) { fp[u] = W.KP + (size_t)b * N * W.kps + e; fst[u] = (size_t)W.kps; }
+    else if (e - KPW < NX) fp[u] = rb + C::R_RC + (e - KPW);
   }
-  auto fetch_fwd = [&](int k) __attribute__((always_inline)) {
-    const size_t o = (size_t)k * sstr;
+  auto fetch_fwd = [&](int) __attribute__((always_inline)) {   // called for k = 0, 1, 2, ... in order
 #pragma unroll
-    for (int u = 0; u < FPL; u++) fv[u] = fp[u][o];
+    for (int u = 0; u < FPL; u++) { fv[u] = *fp[u]; fp[u] += fst[u]; }
   };
   fetch_fwd(0);
   for (int k = 0; k < N; k++) {
@@ -1791,6 +1792,19 @@ struct Carver {
   }
 };
 
+// Host view of the stage-record layout (Cfg::R_* of the model's kernel variant).
+struct RecLayout { int q, c, dg, cs, q0, q1, rc, a5, b5, rw, rs; };
+static RecLayout rec_layout(const DevModel &M) {
+  RecLayout L;
+  const int nq2 = M.n * (M.n + 1) / 2;
+  L.q = 0; L.c = nq2; L.dg = 2 * nq2; L.cs = L.dg + (M.nv - M.n);
+  L.q0 = L.cs + (M.ns > 0 ? M.nv : 0); L.q1 = L.q0 + M.nv; L.rc = L.q1 + M.nv;
+  L.a5 = L.rc + M.nx; L.b5 = L.a5 + 25;
+  L.rw = L.a5 + (M.robot == RMPC_ROBOT_DIFFDRIVE ? 35 : 0);
+  L.rs = (L.rw + 1 + 7) / 8 * 8;
+  return L;
+}
+
 static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W) {
   Carver c(base);
   const size_t S = (size_t)M.N * Bp;  // one slot
@@ -1805,23 +1819,15 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   }
   W.dz = c.take<double>(S * M.nv);
   W.nunew = c.take<double>(S * M.nx);
-  W.Qqq = c.take<double>(S * nq2);
-  W.Cqq = c.take<double>(S * nq2);
-  W.Dg = c.take<double>(S * (M.nv - nq));
-  W.cs = c.take<double>(S * M.nv);
-  W.q0 = c.take<double>(S * M.nv);
-  W.q1 = c.take<double>(S * M.nv);
+  W.rs = rec_layout(M).rs;
+  W.R = c.take<double>(S * W.rs);
   W.gfa = c.take<double>(S * M.nv);
   for (int i = 0; i < 2; i++) {
     W.grow[i] = c.take<double>(S * (M.nh > 0 ? M.nh : 1));
     W.Jq[i] = c.take<double>(S * (M.nfk > 0 ? M.nfk * nq : 1));
   }
-  W.rc = c.take<double>(S * M.nx);
-  W.A5 = c.take<double>(S * 25);
-  W.B5 = c.take<double>(S * 10);
-  W.Kg = c.take<double>(S * M.nw * M.nx);
-  W.kff = c.take<double>(S * M.nw);
-  W.Pst = c.take<double>(S * (M.nx * (M.nx + 1) / 2 + M.nx));
+  W.kps = (M.nw * M.nx + M.nw + M.nx * M.nx + M.nx + 7) / 8 * 8;
+  W.KP = c.take<double>(S * W.kps);
   W.zeros = c.take<double>(S);
   W.part = c.take<double>(S * P_COUNT);
   W.gphi = c.take<double>(S);
@@ -1855,7 +1861,7 @@ static void fill_lane_bytes(rmpc_handle *h, int B) {
   const int64_t sweep_rd = M.nv * 2 + M.m * 2 + M.nfk * (1 + M.n) + M.nx * 4 + M.npar + M.nx * 2 + 2;
   const int64_t sweep_wr = M.nv + 2 * M.m + M.nx + nq2 + (M.use_curv ? nq2 : 0) + (M.nv - M.n) + (M.ns ? M.nv : 0) +
                            3 * M.nv + M.nh + M.nfk * M.n + M.nx + dd + P_COUNT;
-  const int64_t np2 = M.nx * (M.nx + 1) / 2 + M.nx;
+  const int64_t np2 = M.nx * M.nx + M.nx;  // cost-to-go kept dense in the gain record
   const int64_t curv = M.use_curv ? nq2 : 0;
   const int64_t ric_rd = P_COUNT + 3 + (nq2 + curv + (M.nv - M.n) + (M.ns ? M.nv : 0) + 2 * M.nv) + 2 * M.nx + 2 * dd +
                          (M.nw * M.nx + M.nw) + np2;
@@ -1880,6 +1886,7 @@ template <class C>
 static void launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hipStream_t st, int which) {
   const int B = ph.B;
   const int lanes = ph.W.Bp * h->M.N;
+  if (ph.W.rs != C::RS) { fprintf(stderr, "rmpc: stage-record layout mismatch (%d != %d)\n", ph.W.rs, C::RS); abort(); }
   if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, ph.W, B, first);
   else if (which == K_RICCATI) {
     if (B >= kGroupedMin)
@@ -2261,13 +2268,14 @@ int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x
     HIPCHK(hipMemcpy(v.data(), dptr, sizeof(double) * S * slots, hipMemcpyDeviceToHost));
     return 0;
   };
-  std::vector<double> Qqq, Dg, cs, q0, q1, rc, gr, part;
-  const int nq = M.n, nq2 = nq * (nq + 1) / 2, nv = M.nv;
-  if (fetch(h->W.Qqq, nq2, Qqq) || fetch(h->W.Dg, nv - nq, Dg) || fetch(h->W.cs, nv, cs) || fetch(h->W.q0, nv, q0) ||
-      fetch(h->W.q1, nv, q1) || fetch(h->W.rc, M.nx, rc) || fetch(h->W.grow[1], M.nh > 0 ? M.nh : 1, gr)  /* first pass: cur = 0, written to buffer 1 */ ||
+  std::vector<double> R, gr, part;
+  const int nq = M.n, nv = M.nv;
+  const RecLayout L = rec_layout(M);
+  if (fetch(h->W.R, L.rs, R) || fetch(h->W.grow[1], M.nh > 0 ? M.nh : 1, gr)  /* first pass: cur = 0, written to buffer 1 */ ||
       fetch(h->W.part, P_COUNT, part))
     return -1;
   auto at = [&](const std::vector<double> &v, int slot, int k, int b) { return v[((size_t)slot * M.N + k) * h->Bp + b]; };
+  auto rec = [&](int off, int k, int b) { return R[((size_t)b * M.N + k) * L.rs + off]; };
   for (int b = 0; b < B; b++)
     for (int k = 0; k < M.N; k++) {
       const size_t sb = (size_t)b * M.N + k;
@@ -2276,17 +2284,17 @@ int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x
         for (int i = 0; i < nv * nv; i++) Q[i] = 0.0;
         int s = 0;
         for (int a = 0; a < nq; a++)
-          for (int c = a; c < nq; c++) { double v = at(Qqq, s++, k, b); Q[a * nv + c] = v; Q[c * nv + a] = v; }
-        for (int j = nq; j < nv; j++) Q[j * nv + j] = at(Dg, j - nq, k, b);
+          for (int c = a; c < nq; c++) { double v = rec(L.q + s++, k, b); Q[a * nv + c] = v; Q[c * nv + a] = v; }
+        for (int j = nq; j < nv; j++) Q[j * nv + j] = rec(L.dg + j - nq, k, b);
         if (M.ns)
           for (int j = 0; j < nv; j++)
-            if (j != M.nx) { double v = at(cs, j, k, b); Q[j * nv + M.nx] = v; Q[M.nx * nv + j] = v; }
+            if (j != M.nx) { double v = rec(L.cs + j, k, b); Q[j * nv + M.nx] = v; Q[M.nx * nv + j] = v; }
       }
       for (int j = 0; j < nv; j++) {
-        if (out_q0) out_q0[sb * nv + j] = at(q0, j, k, b);
-        if (out_q1) out_q1[sb * nv + j] = at(q1, j, k, b);
+        if (out_q0) out_q0[sb * nv + j] = rec(L.q0 + j, k, b);
+        if (out_q1) out_q1[sb * nv + j] = rec(L.q1 + j, k, b);
       }
-      if (out_rc) for (int j = 0; j < M.nx; j++) out_rc[sb * M.nx + j] = (k < M.N - 1) ? at(rc, j, k, b) : 0.0;
+      if (out_rc) for (int j = 0; j < M.nx; j++) out_rc[sb * M.nx + j] = (k < M.N - 1) ? rec(L.rc + j, k, b) : 0.0;
       if (out_g) for (int j = 0; j < M.nh; j++) out_g[sb * M.nh + j] = at(gr, j, k, b);
       if (out_f) out_f[sb] = at(part, P_F, k, b);
     }

@@ -113,6 +113,22 @@ struct Cfg {
   // k_riccati: no register cap -- at 96 VGPRs (five wavefronts per SIMD) the recursion spills inside its
   // stage loop and runs 30 % slower (measured, cfg2)
   static constexpr int RIC_WPE = 1;
+  // Stage record handed from k_sweep to k_riccati, one per (instance, stage), instance-major:
+  //   Qqq (upper triangle) | Cqq | Dg (variables >= NQ) | cs (softened models) | q0 | q1 | rc | A5 B5 (diff-drive)
+  // A lane of k_sweep scatters its stage's entries into the record; a wavefront of k_riccati then
+  // fetches a whole record with one contiguous request instead of one cache line per entry.
+  static constexpr int R_Q = 0;
+  static constexpr int R_C = R_Q + NQ2;
+  static constexpr int R_DG = R_C + NQ2;
+  static constexpr int R_CS = R_DG + (NV - NQ_);
+  static constexpr int R_Q0 = R_CS + (NS_ > 0 ? NV : 0);
+  static constexpr int R_Q1 = R_Q0 + NV;
+  static constexpr int R_RC = R_Q1 + NV;
+  static constexpr int R_A5 = R_RC + NX;
+  static constexpr int R_B5 = R_A5 + 25;
+  static constexpr int RW = R_A5 + (ROBOT_ == RMPC_ROBOT_DIFFDRIVE ? 35 : 0);
+  static constexpr int R_ZERO = RW;             // always 0.0: source of the structural zeros of the dense blocks
+  static constexpr int RS = (RW + 1 + 7) / 8 * 8;   // record stride (doubles)
 };
 
 // ---------------------------------------------------------------------------
