@@ -909,11 +909,21 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   const double cwt = usec ? 1.0 : 0.0;  // Cqq is zero-filled when the model does not use it
 
   // ---- LDS images -------------------------------------------------------------------------
-  constexpr int LDSW = NX * NX + NX + NX * NV + NV * NV + NV + NX * NV + NX + NX + NW * NX + NW + NX + NW;
+  // img = [K | kff | P (upper triangle) | p | rc]: what the forward pass needs of a stage, contiguous in
+  // LDS so that it leaves for (and returns from) the instance's gain record KP in one request
+  constexpr int NP2 = NX * (NX + 1) / 2;
+  constexpr int KPW = NW * NX + NW + NP2 + NX + NX;
+  constexpr int KPL = (KPW + 63) / 64;
+  constexpr int LDSW = KPW + NX * NX + NX * NV + NV * NV + NV + NX * NV + NX + NX + NW + C::RS;
   __shared__ double lds[IPB][LDSW];
-  double *const sP = lds[wv], *const sp = sP + NX * NX, *const sAB = sp + NX, *const sQ = sAB + NX * NV,
-               *const sq = sQ + NV * NV, *const sT = sq + NV, *const sPc = sT + NX * NV, *const src = sPc + NX,
-               *const sK = src + NX, *const skf = sK + NW * NX, *const sdx = skf + NW, *const sdw = sdx + NX;
+  double *const img = lds[wv], *const sK = img, *const skf = sK + NW * NX, *const sPt = skf + NW, *const sp = sPt + NP2,
+               *const src = sp + NX, *const sP = img + KPW, *const sAB = sP + NX * NX, *const sQ = sAB + NX * NV,
+               *const sq = sQ + NV * NV, *const sT = sq + NV, *const sPc = sT + NX * NV, *const sdx = sPc + NX,
+               *const sdw = sdx + NX, *const srec = sdw + NW;   // srec: the stage record as fetched
+  auto tri = [](int i, int j) __attribute__((always_inline)) {   // index of (i, j) in the packed upper triangle
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    return lo * NX - lo * (lo - 1) / 2 + (hi - lo);
+  };
   const double h = M.dt, h2 = 0.5 * M.dt * M.dt;
 
   // [A | B] of the holonomic chain is constant: A = [I hI; 0 I], B = [h2 I; h I] on the u columns
@@ -942,57 +952,56 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   constexpr int EPL = (NV * NV + 63) / 64;   // stage Hessian entries per lane
   constexpr int TPL = (NX * NV + 63) / 64;   // entries of T = P [A|B] (and of [A|B]) per lane
   constexpr int PPL = (NX * NX + 63) / 64;   // entries of P per lane
-  const double *qp[EPL], *cp[EPL];
+  constexpr int RPL = (C::RS + 63) / 64;     // record entries per lane
+  int qp[EPL], cp[EPL];                      // record entries a dense-block entry of this lane is made of
 #pragma unroll
   for (int u = 0; u < EPL; u++) {
     const int e = lane + 64 * u;
-    qp[u] = zer; cp[u] = zer;
+    qp[u] = C::R_ZERO; cp[u] = C::R_ZERO;
     if (e < NV * NV) {
       const int i = e / NV, j = e - i * NV;
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       if (hi < NQ) {
         const int s = lo * NQ - lo * (lo - 1) / 2 + (hi - lo);
-        qp[u] = rb + C::R_Q + s;
-        if constexpr (C::CURV) cp[u] = rb + C::R_C + s;
+        qp[u] = C::R_Q + s;
+        if constexpr (C::CURV) cp[u] = C::R_C + s;
       } else if (lo == hi) {
-        qp[u] = rb + C::R_DG + (lo - NQ);
+        qp[u] = C::R_DG + (lo - NQ);
       } else if (NS > 0 && lo == NX) {
-        qp[u] = rb + C::R_CS + hi;
+        qp[u] = C::R_CS + hi;
       } else if (NS > 0 && hi == NX) {
-        qp[u] = rb + C::R_CS + lo;
+        qp[u] = C::R_CS + lo;
       }
     }
   }
-  const double *q0p = lane < NV ? rb + C::R_Q0 + lane : zer;
-  const double *q1p = lane < NV ? rb + C::R_Q1 + lane : zer;
-  const double *rcp = lane < NX ? rb + C::R_RC + lane : zer;
   // [A|B] of the diff-drive model: identity outside the reduced (x, y, theta, v, omega) block
-  const double *abp[DD ? TPL : 1];
+  int abp[DD ? TPL : 1];
   double abc[DD ? TPL : 1];
   if constexpr (DD) {
 #pragma unroll
     for (int u = 0; u < TPL; u++) {
       const int e = lane + 64 * u;
-      abp[u] = zer; abc[u] = 0.0;
+      abp[u] = C::R_ZERO; abc[u] = 0.0;
       if (e < NX * NV) {
         const int i = e / NV, j = e - i * NV;
         const int ri = (i < 3) ? i : (i >= 6 ? i - 3 : -1);
         if (j < NX) {
           const int rj = (j < 3) ? j : (j >= 6 ? j - 3 : -1);
-          if (ri >= 0 && rj >= 0) abp[u] = rb + C::R_A5 + (ri * 5 + rj);
+          if (ri >= 0 && rj >= 0) abp[u] = C::R_A5 + (ri * 5 + rj);
           else abc[u] = (i == j) ? 1.0 : 0.0;
         } else if (j >= NX + NS && ri >= 0) {
-          abp[u] = rb + C::R_B5 + (ri * 2 + (j - NX - NS));
+          abp[u] = C::R_B5 + (ri * 2 + (j - NX - NS));
         }
       }
     }
   }
-  auto fill_AB_dd = [&](int k) __attribute__((always_inline)) {
+  // [A|B] of the stage whose record is in srec
+  auto fill_AB_dd = [&]() __attribute__((always_inline)) {
     if constexpr (DD) {
 #pragma unroll
       for (int u = 0; u < TPL; u++) {
         const int e = lane + 64 * u;
-        const double v = abp[u][(size_t)k * sstr] + abc[u];
+        const double v = srec[abp[u]] + abc[u];
         if (e < NX * NV) sAB[e] = v;
       }
     }
@@ -1003,28 +1012,50 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   if (lane < NX) sp[lane] = 0.0;
   bool chol_ok = true;
 
-  // prefetched inputs of the stage about to be processed
-  double qv[EPL], qlin = 0.0, rcv = 0.0;
+  // prefetched record of the stage about to be processed (lane e holds entry e)
+  double recv[RPL];
   auto fetch_stage = [&](int k) __attribute__((always_inline)) {
-    const size_t o = (size_t)k * sstr;
 #pragma unroll
-    for (int u = 0; u < EPL; u++) qv[u] = qp[u][o] - cwt * cp[u][o];
-    qlin = q0p[o] - mu * q1p[o];
-    rcv = rcp[o];   // stage N-1: finite, unused
+    for (int u = 0; u < RPL; u++) {
+      const int e = lane + 64 * u;
+      recv[u] = rb[(size_t)k * sstr + (e < C::RS ? e : 0)];
+    }
   };
   fetch_stage(N - 1);
   for (int k = N - 1; k >= 0; k--) {
-    double *const kpr = W.KP + ((size_t)b * N + k) * W.kps;   // this stage's gain / cost-to-go record
-    // -- fill ------------------------------------------------------------------------------
+    // -- the image of stage k+1 is complete: it leaves for the gain record (read now, stored after the
+    //    barrier); the stage record goes to LDS, the request for the next one leaves ----------------
+    double kpv[KPL];
+#pragma unroll
+    for (int u = 0; u < KPL; u++) {
+      const int e = lane + 64 * u;
+      kpv[u] = img[e < KPW ? e : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < RPL; u++) {
+      const int e = lane + 64 * u;
+      if (e < C::RS) srec[e] = recv[u];
+    }
+    if (k > 0) fetch_stage(k - 1);  // travels while this stage is computed
+    WSYNC();
+    if (k < N - 1) {
+      double *const kp1 = W.KP + ((size_t)b * N + (k + 1)) * W.kps;
+#pragma unroll
+      for (int u = 0; u < KPL; u++) {
+        const int e = lane + 64 * u;
+        if (e < KPW) kp1[e] = kpv[u];
+      }
+    }
+    // -- fill: dense stage Hessian, gradient, defect (rc of stage N-1: finite, unused) ---------------
 #pragma unroll
     for (int u = 0; u < EPL; u++) {
       const int e = lane + 64 * u;
-      if (e < NV * NV) sQ[e] = qv[u];
+      const double v = srec[qp[u]] - cwt * srec[cp[u]];
+      if (e < NV * NV) sQ[e] = v;
     }
-    if (lane < NV) sq[lane] = qlin;
-    if (lane < NX) src[lane] = rcv;
-    if (k < N - 1) fill_AB_dd(k);
-    if (k > 0) fetch_stage(k - 1);  // requests for the next stage travel while this one is computed
+    if (lane < NV) sq[lane] = srec[C::R_Q0 + lane] - mu * srec[C::R_Q1 + lane];
+    if (lane < NX) src[lane] = srec[C::R_RC + lane];
+    if (k < N - 1) fill_AB_dd();
     WSYNC();
     if (k < N - 1) {
       if constexpr (!DD) {
@@ -1139,10 +1170,10 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
       chol_solve<NW>(L, invd, col);
       if (lane < NX) {
 #pragma unroll
-        for (int i = 0; i < NW; i++) { sK[i * NX + lane] = col[i]; kpr[i * NX + lane] = col[i]; }
+        for (int i = 0; i < NW; i++) sK[i * NX + lane] = col[i];
       } else {
 #pragma unroll
-        for (int i = 0; i < NW; i++) { skf[i] = col[i]; kpr[NW * NX + i] = col[i]; }
+        for (int i = 0; i < NW; i++) skf[i] = col[i];
       }
     }
     WSYNC();
@@ -1175,10 +1206,11 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
       const int e = lane + 64 * u;
       if (e < NX * NX) {
         sP[e] = pn[u];
-        kpr[NW * NX + NW + e] = pn[u];
+        const int i = e / NX, j = e - i * NX;
+        if (i <= j) sPt[tri(i, j)] = pn[u];
       }
     }
-    if (lane < NX) { sp[lane] = pnv; kpr[NW * NX + NW + NX * NX + lane] = pnv; }
+    if (lane < NX) sp[lane] = pnv;
     // (the fill of the next stage touches sQ / sq / src only; its barrier orders the sP writes)
   }
   if (!chol_ok) {
@@ -1195,55 +1227,58 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   if (L0) W.usedc[b] = usec ? 1 : 0;
 
   // ---- forward rollout + costates nu+_k = P_k dx_k + p_k ------------------------------------------
-  // gains and cost-to-go of stage 0 are still in LDS; later stages are re-read (one element per lane)
+  // the image of stage 0 is still in LDS; later stages come back from the gain record (one request each)
   WSYNC();
   if (lane < NX) sdx[lane] = 0.0;
-  constexpr int FPL = (NW * NX + NW + NX * NX + NX + NX + 63) / 64;
-  double fv[FPL];
-  const double *fp[FPL];   // running pointers: record entries advance by the record stride, rc by the stage stride
-  size_t fst[FPL];
-  constexpr int KPW = NW * NX + NW + NX * NX + NX;
+  double fv[KPL];
+  const double *const kpb = W.KP + (size_t)b * N * W.kps;
+  auto fetch_fwd = [&](int k) __attribute__((always_inline)) {
 #pragma unroll
-  for (int u = 0; u < FPL; u++) {
-    const int e = lane + 64 * u;
-    fp[u] = zer; fst[u] = sstr;
-    if (e < KPW) { fp[u] = W.KP + (size_t)b * N * W.kps + e; fst[u] = (size_t)W.kps; }
-    else if (e - KPW < NX) fp[u] = rb + C::R_RC + (e - KPW);
-  }
-  auto fetch_fwd = [&](int) __attribute__((always_inline)) {   // called for k = 0, 1, 2, ... in order
-#pragma unroll
-    for (int u = 0; u < FPL; u++) { fv[u] = *fp[u]; fp[u] += fst[u]; }
-  };
-  fetch_fwd(0);
-  for (int k = 0; k < N; k++) {
-#pragma unroll
-    for (int u = 0; u < FPL; u++) {
-      int e = lane + 64 * u;
-      if (e < NW * NX) sK[e] = fv[u];
-      else if ((e -= NW * NX) < NW) skf[e] = fv[u];
-      else if ((e -= NW) < NX * NX) sP[e] = fv[u];
-      else if ((e -= NX * NX) < NX) sp[e] = fv[u];
-      else if ((e -= NX) < NX) src[e] = fv[u];
+    for (int u = 0; u < KPL; u++) {
+      const int e = lane + 64 * u;
+      fv[u] = kpb[(size_t)k * W.kps + (e < KPW ? e : 0)];
     }
-    if (k < N - 1) fill_AB_dd(k);
-    if (k < N - 1) fetch_fwd(k + 1);
+  };
+  if (N > 1) fetch_fwd(1);
+  for (int k = 0; k < N; k++) {
+    if (k > 0) {
+#pragma unroll
+      for (int u = 0; u < KPL; u++) {
+        const int e = lane + 64 * u;
+        if (e < KPW) img[e] = fv[u];
+      }
+    }
+    if constexpr (DD) {
+      if (k < N - 1) {   // [A|B] of stage k straight from its record (diff-drive only)
+#pragma unroll
+        for (int u = 0; u < TPL; u++) {
+          const int e = lane + 64 * u;
+          const double v = rb[(size_t)k * sstr + abp[u]] + abc[u];
+          if (e < NX * NV) sAB[e] = v;
+        }
+      }
+    }
+    if (k > 0 && k < N - 1) fetch_fwd(k + 1);
     WSYNC();
+    double dzv = 0.0;
     if (lane < NW) {
       double s = skf[lane];
 #pragma unroll
       for (int j = 0; j < NX; j++) s += sK[lane * NX + j] * sdx[j];
       sdw[lane] = s;
-      W.dz[IDX(NX + lane, k, b)] = s;
+      dzv = s;
     } else if (lane < NW + NX) {
       const int i = lane - NW;
-      W.dz[IDX(i, k, b)] = sdx[i];
+      dzv = sdx[i];
       if (k >= 1) {
         double s = sp[i];
 #pragma unroll
-        for (int j = 0; j < NX; j++) s += sP[i * NX + j] * sdx[j];
+        for (int j = 0; j < NX; j++) s += sPt[tri(i, j)] * sdx[j];
         W.nunew[IDX(i, k, b)] = s;
       }
     }
+    // dz of the stage in one request: lanes < NW hold dw (slots NX..), the next NX lanes dx (slots 0..)
+    if (lane < NW + NX) W.dz[IDX(lane < NW ? NX + lane : lane - NW, k, b)] = dzv;
     WSYNC();
     double dxn = 0.0;
     if (k < N - 1 && lane < NX) {
@@ -1826,7 +1861,7 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
     W.grow[i] = c.take<double>(S * (M.nh > 0 ? M.nh : 1));
     W.Jq[i] = c.take<double>(S * (M.nfk > 0 ? M.nfk * nq : 1));
   }
-  W.kps = (M.nw * M.nx + M.nw + M.nx * M.nx + M.nx + 7) / 8 * 8;
+  W.kps = (M.nw * M.nx + M.nw + M.nx * (M.nx + 1) / 2 + M.nx + M.nx + 7) / 8 * 8;
   W.KP = c.take<double>(S * W.kps);
   W.zeros = c.take<double>(S);
   W.part = c.take<double>(S * P_COUNT);
@@ -1861,7 +1896,7 @@ static void fill_lane_bytes(rmpc_handle *h, int B) {
   const int64_t sweep_rd = M.nv * 2 + M.m * 2 + M.nfk * (1 + M.n) + M.nx * 4 + M.npar + M.nx * 2 + 2;
   const int64_t sweep_wr = M.nv + 2 * M.m + M.nx + nq2 + (M.use_curv ? nq2 : 0) + (M.nv - M.n) + (M.ns ? M.nv : 0) +
                            3 * M.nv + M.nh + M.nfk * M.n + M.nx + dd + P_COUNT;
-  const int64_t np2 = M.nx * M.nx + M.nx;  // cost-to-go kept dense in the gain record
+  const int64_t np2 = M.nx * (M.nx + 1) / 2 + M.nx + M.nx;  // cost-to-go (packed), p and rc in the gain record
   const int64_t curv = M.use_curv ? nq2 : 0;
   const int64_t ric_rd = P_COUNT + 3 + (nq2 + curv + (M.nv - M.n) + (M.ns ? M.nv : 0) + 2 * M.nv) + 2 * M.nx + 2 * dd +
                          (M.nw * M.nx + M.nw) + np2;
