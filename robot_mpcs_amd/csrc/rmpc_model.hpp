@@ -107,9 +107,10 @@ struct Cfg {
   static constexpr bool CURV = (ROBOT_ == RMPC_ROBOT_CHAIN) && (NS_ == 0) && (NQ_ <= 3);
   // instances (wavefronts) per block of the Riccati kernel: neighbours share cache lines
   static constexpr int IPB = (NX > 8) ? 8 : 16;
-  // k_sweep register budget: two wavefronts per SIMD (256 VGPRs) for the three-joint robots -- a
-  // few spilled doubles cost less than half the latency hiding; the arm needs the whole file
-  static constexpr int SWEEP_WPE = (NQ > 3) ? 1 : 2;
+  // k_sweep register budget: uncapped (one wavefront per SIMD, ~390 VGPRs, no spills).  A 256-VGPR cap (two
+  // wavefronts per SIMD) shortens a lone sweep slightly but spills and fills every register file, so that no
+  // wavefront of another batch's k_riccati (96 VGPRs) can run beside it: -13 % throughput with four batches in flight
+  static constexpr int SWEEP_WPE = 1;
   // k_riccati: no register cap -- at 96 VGPRs (five wavefronts per SIMD) the recursion spills inside its
   // stage loop and runs 30 % slower (measured, cfg2)
   static constexpr int RIC_WPE = 1;
