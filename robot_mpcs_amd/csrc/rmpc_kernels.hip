@@ -762,7 +762,9 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   // the grouped one (IPB = C::IPB) while many instances iterate, the one-wave blocks (IPB = 1,
   // static LDS addresses, lowest latency) in the iteration tail.
   const int nact = *W.n_act;
-  if ((IPB > 1) != (nact >= kGroupedMin)) return;
+  if constexpr (C::IPB > 1) {
+    if ((IPB > 1) != (nact >= kGroupedMin)) return;
+  }
   const int wv = threadIdx.x >> 6;
   const int li = blockIdx.x * IPB + wv;
   if (li >= nact) return;
@@ -1924,9 +1926,9 @@ static void launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hi
   if (ph.W.rs != C::RS) { fprintf(stderr, "rmpc: stage-record layout mismatch (%d != %d)\n", ph.W.rs, C::RS); abort(); }
   if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, ph.W, B, first);
   else if (which == K_RICCATI) {
-    if (B >= kGroupedMin)
+    if (C::IPB > 1 && B >= kGroupedMin)
       hipLaunchKernelGGL((k_riccati<C, C::IPB>), dim3((B + C::IPB - 1) / C::IPB), dim3(64 * C::IPB), 0, st, h->M, ph.W, B, first, pass);
-    const int tail_blocks = B < kGroupedMin ? B : kGroupedMin;
+    const int tail_blocks = (C::IPB == 1 || B < kGroupedMin) ? B : kGroupedMin;
     hipLaunchKernelGGL((k_riccati<C, 1>), dim3(tail_blocks), dim3(64), 0, st, h->M, ph.W, B, first, pass);
   }
   else hipLaunchKernelGGL((k_step<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, ph.W, B);

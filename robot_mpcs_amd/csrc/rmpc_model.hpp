@@ -105,14 +105,17 @@ struct Cfg {
   static constexpr int NQ2 = NQ_ * (NQ_ + 1) / 2;
   static constexpr int NR = 5;  // reduced diff-drive state (x, y, theta, v, omega)
   static constexpr bool CURV = (ROBOT_ == RMPC_ROBOT_CHAIN) && (NS_ == 0) && (NQ_ <= 3);
-  // instances (wavefronts) per block of the Riccati kernel: neighbours share cache lines
-  static constexpr int IPB = (NX > 8) ? 8 : 16;
+  // instances (wavefronts) per block of the grouped Riccati kernel.  Small blocks: with the instance-major
+  // records neighbouring instances no longer share cache lines, a 4-wavefront block fits beside a k_sweep
+  // wavefront of another batch on every SIMD (a 16-wavefront block needs four free slots per SIMD at once);
+  // the arm runs one-wavefront blocks only (no 512-thread register limit, no spills, one launch per pass)
+  static constexpr int IPB = (NX > 8) ? 1 : 4;
   // k_sweep register budget: uncapped (one wavefront per SIMD, ~390 VGPRs, no spills).  A 256-VGPR cap (two
   // wavefronts per SIMD) shortens a lone sweep slightly but spills and fills every register file, so that no
   // wavefront of another batch's k_riccati (96 VGPRs) can run beside it: -13 % throughput with four batches in flight
   static constexpr int SWEEP_WPE = 1;
-  // k_riccati: no register cap -- at 96 VGPRs (five wavefronts per SIMD) the recursion spills inside its
-  // stage loop and runs 30 % slower (measured, cfg2)
+  // k_riccati: no register cap (94 VGPRs for the point robot) -- at 80 the recursion spills inside its stage
+  // loop: -3 % throughput on cfg2, -20 % on cfg3 (measured)
   static constexpr int RIC_WPE = 1;
   // Stage record handed from k_sweep to k_riccati, one per (instance, stage), instance-major:
   //   Qqq (upper triangle) | Cqq | Dg (variables >= NQ) | cs (softened models) | q0 | q1 | rc | A5 B5 (diff-drive)
