@@ -219,7 +219,8 @@ def main():
                     "all_kernels": {k: {"total_ms": round(p["total_ms"], 3), "launches": int(p["launches"]),
                                         "avg_ms": (p["total_ms"] / p["launches"]) if p["launches"] else None,
                                         "alg_GBps": (p["total_alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9)
-                                        if p["launches"] and p["total_ms"] > 0 else None}
+                                        if p["launches"] and p["total_ms"] > 0 else None,
+                                        "alg_bytes_full_launch": int(p["full_launch_bytes"])}
                                     for k, p in prof.items()},
                 }
         # ---- CPU baseline: the oracle port on this box's host cores, same inputs ----

@@ -1896,13 +1896,13 @@ static void fill_lane_bytes(rmpc_handle *h, int B) {
   const int nq2 = M.n * (M.n + 1) / 2;
   const int64_t dd = (M.robot == RMPC_ROBOT_DIFFDRIVE) ? 35 : 0;
   const int64_t sweep_rd = M.nv * 2 + M.m * 2 + M.nfk * (1 + M.n) + M.nx * 4 + M.npar + M.nx * 2 + 2;
-  const int64_t sweep_wr = M.nv + 2 * M.m + M.nx + nq2 + (M.use_curv ? nq2 : 0) + (M.nv - M.n) + (M.ns ? M.nv : 0) +
-                           3 * M.nv + M.nh + M.nfk * M.n + M.nx + dd + P_COUNT;
-  const int64_t np2 = M.nx * (M.nx + 1) / 2 + M.nx + M.nx;  // cost-to-go (packed), p and rc in the gain record
-  const int64_t curv = M.use_curv ? nq2 : 0;
-  const int64_t ric_rd = P_COUNT + 3 + (nq2 + curv + (M.nv - M.n) + (M.ns ? M.nv : 0) + 2 * M.nv) + 2 * M.nx + 2 * dd +
-                         (M.nw * M.nx + M.nw) + np2;
-  const int64_t ric_wr = (M.nw * M.nx + M.nw) + np2 + M.nv + M.nx;
+  // stage record (k_sweep -> k_riccati): Qqq, Cqq, Dg, cs, q0, q1, rc, A5 B5, zero slot
+  const int64_t rec = 2 * nq2 + (M.nv - M.n) + (M.ns ? M.nv : 0) + 2 * M.nv + M.nx + dd + 1;
+  const int64_t sweep_wr = M.nv + 2 * M.m + M.nx + rec + M.nv + M.nh + M.nfk * M.n + P_COUNT;
+  // gain record (k_riccati backward -> forward): K, kff, P (packed), p, rc
+  const int64_t kpw = M.nw * M.nx + M.nw + M.nx * (M.nx + 1) / 2 + 2 * M.nx;
+  const int64_t ric_rd = P_COUNT + 3 + rec + kpw + dd;
+  const int64_t ric_wr = kpw + M.nv + M.nx;
   const int64_t step_rd = 3 * M.nv + 2 * M.m + M.nh + M.nfk * M.n;
   const int64_t step_wr = 3;  // gphi and two atomic minima (the row steps are recomputed by k_sweep, not stored)
   h->lane_bytes[K_PACK] = 16 * ((int64_t)B * (M.nx + (int64_t)M.N * (M.nv + M.npar)));

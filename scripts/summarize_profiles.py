@@ -31,7 +31,12 @@ def short(name):
     return name.split("<")[0].split("(")[0].replace("rmpc::", "")
 
 
-stats = glob.glob(os.path.join(go, f"prof_{tag}", "*", "*kernel_stats.csv"))[0]
+def newest(pattern):
+    # gpurun merges every call's files into gpurun_out/: take the latest collection
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+stats = newest(os.path.join(go, f"prof_{tag}", "*", "*kernel_stats.csv"))
 rows = [r for r in csv.DictReader(open(stats)) if "rmpc::" in r["Name"]]
 with open(os.path.join(pdir, f"{tag}_{cfg}_kernel_stats.csv"), "w") as f:
     w = csv.writer(f)
@@ -41,7 +46,7 @@ with open(os.path.join(pdir, f"{tag}_{cfg}_kernel_stats.csv"), "w") as f:
 
 pmc = {}
 for cname, d in (("FETCH_SIZE", f"pmc_fetch_{tag}"), ("WRITE_SIZE", f"pmc_write_{tag}")):
-    f = glob.glob(os.path.join(go, d, "*", "*counter_collection.csv"))[0]
+    f = newest(os.path.join(go, d, "*", "*counter_collection.csv"))
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == cname and "rmpc::" in r["Kernel_Name"]:
