@@ -224,7 +224,7 @@ def main():
                                     for k, p in prof.items()},
                 }
         # ---- CPU baseline: the oracle port on this box's host cores, same inputs ----
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             from oracle.oracle import Oracle
             cores = os.cpu_count() or 1
             o = Oracle(d)

@@ -8,20 +8,25 @@
 //   k_sweep   one lane per (instance, stage): forms the trial point
 //             z + alpha dz (t, lambda, nu likewise), evaluates dynamics, cost,
 //             inequality rows and their Jacobians there, condenses the barrier
-//             terms into the stage Hessian / gradient blocks and writes the
-//             merit and KKT partial sums of the stage.             [HBM bound]
-//   k_riccati one lane per instance: reduces the stage partials, runs the
-//             Armijo test on the l1 merit, updates the barrier parameter,
-//             checks convergence and runs the block-tridiagonal Riccati
-//             recursion (backward, forward, costates).   [latency / HBM bound]
-//   k_step    one lane per (instance, stage): slack and multiplier steps,
-//             fraction-to-the-boundary partial minima, merit slope partials.
+//             terms into the stage record (Hessian / gradient blocks) and writes
+//             the merit and KKT partial sums of the stage.   [HBM / request bound]
+//   k_riccati one wavefront per instance, stage matrices in LDS: reduces the
+//             stage partials, runs the Armijo test on the l1 merit, updates the
+//             barrier parameter, checks convergence and runs the block-
+//             tridiagonal Riccati recursion (backward, forward, costates).
+//                                    [LDS throughput / LDS round-trip latency]
+//   k_step    one lane per (instance, stage): fraction-to-the-boundary partial
+//             minima of the slack and multiplier steps, merit slope partials.
 //                                                                  [HBM bound]
+//   (+ k_compact: list of the instances still iterating; k_migrate: their move
+//    to a small dense workspace once few are left)
 //
-// Data layout: every array is [slot][stage][instance] with the instance index
-// contiguous (batch-minor structure of arrays), so a wavefront's 64 lanes read
-// 512 contiguous bytes per slot.  Iterates are double buffered per instance
-// (cur / cur^1): a trial point is written once and accepted by flipping a bit.
+// Data layout: what the stage-parallel kernels exchange is [slot][stage][instance]
+// with the instance index contiguous (a wavefront's 64 lanes move 512 contiguous
+// bytes per slot); what the wave-per-instance kernel reads or keeps is
+// [instance][stage][record] (one request per record).  Iterates are double
+// buffered per instance (cur / cur^1): a trial point is written once and
+// accepted by flipping a bit.  DESIGN.md, sections 4 and 5.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -68,7 +73,6 @@ struct Ws {
   double *KP;                     // [Bp][N][kps] per instance and stage: gains K | kff | cost-to-go P (dense) | p --
                                   // private to k_riccati, instance-major so that a wavefront moves a record in one request
   int kps;                        // record stride (doubles, multiple of 8)
-  double *zeros;                 // [N][Bp] zero-filled, never written (source of structural zeros)
   double *part;                   // [P_COUNT][N][Bp]
   double *gphi;                   // [N][Bp]
   unsigned long long *amin_p, *amin_d;  // [Bp] fraction-to-the-boundary step lengths (bits of a positive double)
@@ -1865,7 +1869,6 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   }
   W.kps = (M.nw * M.nx + M.nw + M.nx * (M.nx + 1) / 2 + M.nx + M.nx + 7) / 8 * 8;
   W.KP = c.take<double>(S * W.kps);
-  W.zeros = c.take<double>(S);
   W.part = c.take<double>(S * P_COUNT);
   W.gphi = c.take<double>(S);
   W.amin_p = c.take<unsigned long long>(Bp);
