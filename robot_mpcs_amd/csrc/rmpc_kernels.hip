@@ -932,22 +932,8 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   };
   const double h = M.dt, h2 = 0.5 * M.dt * M.dt;
 
-  // [A | B] of the holonomic chain is constant: A = [I hI; 0 I], B = [h2 I; h I] on the u columns
-  auto fill_AB_chain = [&]() __attribute__((always_inline)) {
-    for (int e = lane; e < NX * NV; e += 64) {
-      const int i = e / NV, j = e - i * NV;
-      double v = 0.0;
-      if (j < NX) {
-        if (i == j) v = 1.0;
-        else if (i < NQ && j == i + NQ) v = h;
-      } else if (j >= NX + NS) {
-        const int c = j - NX - NS;
-        if (i < NQ && c == i) v = h2;
-        else if (i >= NQ && c == i - NQ) v = h;
-      }
-      sAB[e] = v;
-    }
-  };
+  // ([A | B] of the holonomic chain is constant, A = [I hI; 0 I], B = [h2 I; h I] on the u columns: every
+  //  product with it is written out in closed form below and sAB is used by the diff-drive model only)
   // Loop-invariant source of every LDS entry this lane fills: a pointer into the instance's stage
   // records (stage 0; an entry of the record, or its zero slot) plus a constant.  The per-stage fetch
   // is then an unconditional load per entry -- no branch around any load -- and all lanes of the
@@ -957,7 +943,6 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   constexpr size_t sstr = (size_t)C::RS;                  // stage stride of the records
   constexpr int EPL = (NV * NV + 63) / 64;   // stage Hessian entries per lane
   constexpr int TPL = (NX * NV + 63) / 64;   // entries of T = P [A|B] (and of [A|B]) per lane
-  constexpr int PPL = (NX * NX + 63) / 64;   // entries of P per lane
   constexpr int RPL = (C::RS + 63) / 64;     // record entries per lane
   int qp[EPL], cp[EPL];                      // record entries a dense-block entry of this lane is made of
 #pragma unroll
@@ -1013,7 +998,6 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     }
   };
 
-  if constexpr (!DD) fill_AB_chain();
   for (int e = lane; e < NX * NX; e += 64) sP[e] = 0.0;
   if (lane < NX) sp[lane] = 0.0;
   bool chol_ok = true;
@@ -1184,39 +1168,41 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     }
     WSYNC();
     // -- cost-to-go: P = sym(Qxx + Qxw K), p = qx + Qxw kff ---------------------------------------------
-    double pn[PPL], pnv = 0.0;
+    // entries e < NX*NX are P(i, j); the next NX entries are p(i), written as the same expression with the
+    // "column" kff and no transposed partner (a == c, 0.5 (a + a) = a exactly): one instruction stream
+    constexpr int PPL2 = (NX * NX + NX + 63) / 64;
+    double pn[PPL2];
 #pragma unroll
-    for (int u = 0; u < PPL; u++) {
+    for (int u = 0; u < PPL2; u++) {
       const int e = lane + 64 * u;
       pn[u] = 0.0;
-      if (e < NX * NX) {
-        const int i = e / NX, j = e - i * NX;
-        double a = sQ[i * NV + j], c = sQ[j * NV + i];
+      if (e < NX * NX + NX) {
+        const bool isP = e < NX * NX;
+        const int i = isP ? e / NX : e - NX * NX, j = isP ? e - i * NX : 0;
+        const double *const a0 = isP ? sQ + i * NV + j : sq + i;
+        const double *const c0 = isP ? sQ + j * NV + i : sq + i;
+        const double *const cq = isP ? sQ + j * NV + NX : sQ + i * NV + NX;
+        double a = *a0, c = *c0;
 #pragma unroll
         for (int l = 0; l < NW; l++) {
-          a += sQ[i * NV + NX + l] * sK[l * NX + j];
-          c += sQ[j * NV + NX + l] * sK[l * NX + i];
+          a += sQ[i * NV + NX + l] * (isP ? sK[l * NX + j] : skf[l]);
+          c += cq[l] * (isP ? sK[l * NX + i] : skf[l]);
         }
         pn[u] = 0.5 * (a + c);
       }
     }
-    if (lane < NX) {
-      double s = sq[lane];
-#pragma unroll
-      for (int l = 0; l < NW; l++) s += sQ[lane * NV + NX + l] * skf[l];
-      pnv = s;
-    }
     WSYNC();
 #pragma unroll
-    for (int u = 0; u < PPL; u++) {
+    for (int u = 0; u < PPL2; u++) {
       const int e = lane + 64 * u;
       if (e < NX * NX) {
         sP[e] = pn[u];
         const int i = e / NX, j = e - i * NX;
         if (i <= j) sPt[tri(i, j)] = pn[u];
+      } else if (e < NX * NX + NX) {
+        sp[e - NX * NX] = pn[u];
       }
     }
-    if (lane < NX) sp[lane] = pnv;
     // (the fill of the next stage touches sQ / sq / src only; its barrier orders the sP writes)
   }
   if (!chol_ok) {
@@ -1266,21 +1252,22 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     }
     if (k > 0 && k < N - 1) fetch_fwd(k + 1);
     WSYNC();
+    // dw = kff + K dx (lanes < NW) and nu+ = p + P dx (the next NX lanes) as ONE instruction stream: both
+    // are "offset + row . dx" over the image, only the per-lane addresses differ (LDS instruction count
+    // is what bounds this kernel when the whole batch iterates)
     double dzv = 0.0;
-    if (lane < NW) {
-      double s = skf[lane];
+    if (lane < NW + NX) {
+      const bool isw = lane < NW;
+      const int i = isw ? lane : lane - NW;
+      double s = img[isw ? (NW * NX + lane) : (NW * NX + NW + NP2 + i)];
 #pragma unroll
-      for (int j = 0; j < NX; j++) s += sK[lane * NX + j] * sdx[j];
-      sdw[lane] = s;
-      dzv = s;
-    } else if (lane < NW + NX) {
-      const int i = lane - NW;
-      dzv = sdx[i];
-      if (k >= 1) {
-        double s = sp[i];
-#pragma unroll
-        for (int j = 0; j < NX; j++) s += sPt[tri(i, j)] * sdx[j];
-        W.nunew[IDX(i, k, b)] = s;
+      for (int j = 0; j < NX; j++) s += img[isw ? (lane * NX + j) : (NW * NX + NW + tri(i, j))] * sdx[j];
+      if (isw) {
+        sdw[lane] = s;
+        dzv = s;
+      } else {
+        dzv = sdx[i];
+        if (k >= 1) W.nunew[IDX(i, k, b)] = s;
       }
     }
     // dz of the stage in one request: lanes < NW hold dw (slots NX..), the next NX lanes dx (slots 0..)
@@ -1288,12 +1275,23 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     WSYNC();
     double dxn = 0.0;
     if (k < N - 1 && lane < NX) {
-      double s = src[lane];
+      if constexpr (!DD) {
+        // holonomic chain, closed form of rc + [A|B][dx; dw] (same order of the non-zero terms as the dense
+        // product): q rows dx_i + h dx_{n+i} + h2 dw_i, v rows dx_i + h dw_{i-n}
+        const bool isq = lane < NQ;
+        double s = src[lane];
+        s += sdx[lane];
+        s += (isq ? h : 0.0) * sdx[isq ? NQ + lane : lane];
+        s += (isq ? h2 : h) * sdw[NS + (isq ? lane : lane - NQ)];
+        dxn = s;
+      } else {
+        double s = src[lane];
 #pragma unroll
-      for (int j = 0; j < NX; j++) s += sAB[lane * NV + j] * sdx[j];
+        for (int j = 0; j < NX; j++) s += sAB[lane * NV + j] * sdx[j];
 #pragma unroll
-      for (int j = 0; j < NW; j++) s += sAB[lane * NV + NX + j] * sdw[j];
-      dxn = s;
+        for (int j = 0; j < NW; j++) s += sAB[lane * NV + NX + j] * sdw[j];
+        dxn = s;
+      }
     }
     WSYNC();
     if (k < N - 1 && lane < NX) sdx[lane] = dxn;
