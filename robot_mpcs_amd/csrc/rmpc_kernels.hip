@@ -1036,60 +1036,69 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
         if (e < KPW) kp1[e] = kpv[u];
       }
     }
-    // -- fill: dense stage Hessian, gradient, defect (rc of stage N-1: finite, unused) ---------------
+    if constexpr (!DD) {
+      // Holonomic chain: A = [I hI; 0 I], B = [h2 I; h I].  The dense stage Hessian is formed in one step
+      // from the record blocks and [A|B]^T P [A|B] in closed form (each entry from at most four entries of
+      // P: blocks 11, 12, 21, 22 at (ii, jj)); rc of the stage goes into the image (stage N-1: finite, unused).
+      const bool rec_cost = k < N - 1;   // a cost-to-go of stage k+1 exists
 #pragma unroll
-    for (int u = 0; u < EPL; u++) {
-      const int e = lane + 64 * u;
-      const double v = srec[qp[u]] - cwt * srec[cp[u]];
-      if (e < NV * NV) sQ[e] = v;
-    }
-    if (lane < NV) sq[lane] = srec[C::R_Q0 + lane] - mu * srec[C::R_Q1 + lane];
-    if (lane < NX) src[lane] = srec[C::R_RC + lane];
-    if (k < N - 1) fill_AB_dd();
-    WSYNC();
-    if (k < N - 1) {
-      if constexpr (!DD) {
-        // Holonomic chain: A = [I hI; 0 I], B = [h2 I; h I].  [A|B]^T P [A|B] in closed form,
-        // each entry from at most four entries of P (blocks 11, 12, 21, 22 at (ii, jj)).
-#pragma unroll
-        for (int u = 0; u < EPL; u++) {
-          const int e = lane + 64 * u;
-          if (e < NV * NV) {
-            const int i = e / NV, j = e - i * NV;
-            // row / column kind: 0 = q, 1 = v, 2 = u, 3 = slack (no contribution)
-            const int ki = i < NQ ? 0 : (i < NX ? 1 : (i >= NX + NS ? 2 : 3));
-            const int kj = j < NQ ? 0 : (j < NX ? 1 : (j >= NX + NS ? 2 : 3));
-            if (ki != 3 && kj != 3) {
-              const int ii = ki == 0 ? i : (ki == 1 ? i - NQ : i - NX - NS);
-              const int jj = kj == 0 ? j : (kj == 1 ? j - NQ : j - NX - NS);
-              const double p11 = sP[ii * NX + jj], p12 = sP[ii * NX + NQ + jj];
-              const double p21 = sP[(NQ + ii) * NX + jj], p22 = sP[(NQ + ii) * NX + NQ + jj];
-              // left factor: row kind picks the combination of the two block rows
-              //   q: (r1, r2) = (1, 0); v: (h, 1); u: (h2, h)       (rows of [A|B]^T)
-              const double l1 = ki == 0 ? 1.0 : (ki == 1 ? h : h2), l2 = ki == 0 ? 0.0 : (ki == 1 ? 1.0 : h);
-              const double c1 = kj == 0 ? 1.0 : (kj == 1 ? h : h2), c2 = kj == 0 ? 0.0 : (kj == 1 ? 1.0 : h);
-              // sum_{a,b in {1,2}} l_a c_b P_ab
-              sQ[e] += l1 * (c1 * p11 + c2 * p12) + l2 * (c1 * p21 + c2 * p22);
-            }
+      for (int u = 0; u < EPL; u++) {
+        const int e = lane + 64 * u;
+        double v = srec[qp[u]] - cwt * srec[cp[u]];
+        if (e < NV * NV) {
+          const int i = e / NV, j = e - i * NV;
+          // row / column kind: 0 = q, 1 = v, 2 = u, 3 = slack (no contribution)
+          const int ki = i < NQ ? 0 : (i < NX ? 1 : (i >= NX + NS ? 2 : 3));
+          const int kj = j < NQ ? 0 : (j < NX ? 1 : (j >= NX + NS ? 2 : 3));
+          if (rec_cost && ki != 3 && kj != 3) {
+            const int ii = ki == 0 ? i : (ki == 1 ? i - NQ : i - NX - NS);
+            const int jj = kj == 0 ? j : (kj == 1 ? j - NQ : j - NX - NS);
+            const double p11 = sP[ii * NX + jj], p12 = sP[ii * NX + NQ + jj];
+            const double p21 = sP[(NQ + ii) * NX + jj], p22 = sP[(NQ + ii) * NX + NQ + jj];
+            // left factor: row kind picks the combination of the two block rows
+            //   q: (r1, r2) = (1, 0); v: (h, 1); u: (h2, h)       (rows of [A|B]^T)
+            const double l1 = ki == 0 ? 1.0 : (ki == 1 ? h : h2), l2 = ki == 0 ? 0.0 : (ki == 1 ? 1.0 : h);
+            const double c1 = kj == 0 ? 1.0 : (kj == 1 ? h : h2), c2 = kj == 0 ? 0.0 : (kj == 1 ? 1.0 : h);
+            // sum_{a,b in {1,2}} l_a c_b P_ab
+            v += l1 * (c1 * p11 + c2 * p12) + l2 * (c1 * p21 + c2 * p22);
           }
+          sQ[e] = v;
         }
-        if (lane < NX) {
+      }
+      if (lane < NX) {
+        src[lane] = srec[C::R_RC + lane];
+        if (rec_cost) {
           double s = sp[lane];
 #pragma unroll
-          for (int l = 0; l < NX; l++) s += sP[lane * NX + l] * src[l];
+          for (int l = 0; l < NX; l++) s += sP[lane * NX + l] * srec[C::R_RC + l];
           sPc[lane] = s;
         }
-        WSYNC();
-        if (lane < NV) {
-          const int ki = lane < NQ ? 0 : (lane < NX ? 1 : (lane >= NX + NS ? 2 : 3));
-          if (ki != 3) {
-            const int ii = ki == 0 ? lane : (ki == 1 ? lane - NQ : lane - NX - NS);
-            const double l1 = ki == 0 ? 1.0 : (ki == 1 ? h : h2), l2 = ki == 0 ? 0.0 : (ki == 1 ? 1.0 : h);
-            sq[lane] += l1 * sPc[ii] + l2 * sPc[NQ + ii];
-          }
+      }
+      WSYNC();
+      if (lane < NV) {
+        double v = srec[C::R_Q0 + lane] - mu * srec[C::R_Q1 + lane];
+        const int ki = lane < NQ ? 0 : (lane < NX ? 1 : (lane >= NX + NS ? 2 : 3));
+        if (rec_cost && ki != 3) {
+          const int ii = ki == 0 ? lane : (ki == 1 ? lane - NQ : lane - NX - NS);
+          const double l1 = ki == 0 ? 1.0 : (ki == 1 ? h : h2), l2 = ki == 0 ? 0.0 : (ki == 1 ? 1.0 : h);
+          v += l1 * sPc[ii] + l2 * sPc[NQ + ii];
         }
-        WSYNC();
-      } else {
+        sq[lane] = v;
+      }
+      WSYNC();
+    } else {
+      // -- fill: dense stage Hessian, gradient, defect (rc of stage N-1: finite, unused), [A|B] -------
+#pragma unroll
+      for (int u = 0; u < EPL; u++) {
+        const int e = lane + 64 * u;
+        const double v = srec[qp[u]] - cwt * srec[cp[u]];
+        if (e < NV * NV) sQ[e] = v;
+      }
+      if (lane < NV) sq[lane] = srec[C::R_Q0 + lane] - mu * srec[C::R_Q1 + lane];
+      if (lane < NX) src[lane] = srec[C::R_RC + lane];
+      if (k < N - 1) fill_AB_dd();
+      WSYNC();
+      if (k < N - 1) {
       // -- T = P [A|B], Pc = P rc + p ---------------------------------------------------------
 #pragma unroll
       for (int u = 0; u < TPL; u++) {
