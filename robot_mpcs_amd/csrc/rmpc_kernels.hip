@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
   double *__restrict__ jqn = W.Jq[nxt];
   const double *__restrict__ nup = W.nunew;
   const double mu = W.mu[b];
-  double *__restrict__ rec = W.R + ((size_t)b * N + k) * W.rs;   // this lane's stage record
+  double *__restrict__ rec = (double *)__builtin_assume_aligned(W.R, 128) + ((size_t)b * N + k) * C::RS;   // this lane's stage record (64-byte aligned: neighbouring entries leave as 16-byte stores)
 
   // ---- step lengths of this trial --------------------------------------
   // null pass: the current point is re-evaluated unchanged so that the step can be
