@@ -250,6 +250,16 @@ __global__ __launch_bounds__(64) void k_migrate(const Ws S, const Ws D, int n, i
   }
 }
 
+// 1/x for normal positive x: hardware estimate + two Newton steps (about 1 ulp; a full fp64 division costs three
+// times as many instructions and the sweep performs one or two per constraint row)
+__device__ __forceinline__ double frcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+
 // compile-time loop: fn(integral_constant<int, L>) ... fn(integral_constant<int, H-1>)
 template <int L, class F, int... I>
 __device__ __forceinline__ void for_range_impl(F &&fn, std::integer_sequence<int, I...>) {
@@ -361,7 +371,11 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
     for (int c = 0; c < NQ; c++) Qqq[a][c] = 0;
   double f = 0.0;
   int bad = 0;
-  double theta = 0.0, logsum = 0.0, rineq = 0.0, rcomp = 0.0, sumc = 0.0, minc = 1e300;
+  double theta = 0.0, rineq = 0.0, rcomp = 0.0, sumc = 0.0, minc = 1e300;
+  // sum of log t over the rows, kept as log(prod of mantissas) + ln2 * (sum of exponents): one log per lane
+  // instead of one per row (a software log is ~70 instructions; the rows of a stage are the bulk of this kernel)
+  double lprod = 1.0;
+  int lexp = 0;
 
   // ---- control effort and slack penalty (ObjectiveManager.py:28-42) ----------
 #pragma unroll
@@ -392,7 +406,7 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
       lv = mu / tv;
     } else {
       const double dtv = gdz + (gold - tcv);
-      const double dlv = (mu - tcv * lcv - lcv * dtv) / tcv;
+      const double dlv = (mu - tcv * lcv - lcv * dtv) * frcp(tcv);
       tv = tcv + am * dtv;
       lv = lcv + dm * dlv;
     }
@@ -400,13 +414,18 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
     ln[IDX(i, k, b)] = lv;
     const double rg = g - tv;
     theta += fabs(rg);
-    logsum += log(tv);
+    if (!(tv > 0.0)) bad = 1;   // (cannot happen: fraction to the boundary; keeps the product's sign meaningful)
+    {
+      int ex;
+      lprod *= frexp(tv, &ex);
+      lexp += ex;
+    }
     rineq = fmax(rineq, fabs(rg));
     const double cmp = tv * lv;
     rcomp = fmax(rcomp, cmp);
     sumc += cmp;
     minc = fmin(minc, cmp);
-    const double it = 1.0 / tv;
+    const double it = frcp(tv);
     return {lv * it, lv * rg * it, it, lv};
   };
 
@@ -747,6 +766,7 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
       for (int c = a; c < NQ; c++) rec[C::R_C + s++] = (C::CURV && M.use_curv) ? Cqq[C::CURV ? a : 0][C::CURV ? c : 0] : 0.0;
   }
   rec[C::R_ZERO] = 0.0;
+  const double logsum = log(lprod) + 0.6931471805599453094 * (double)lexp;
   if (!isfinite(f) || !isfinite(theta) || !isfinite(logsum)) bad = 1;
   W.part[IDX(P_F, k, b)] = f;
   W.part[IDX(P_TH, k, b)] = theta;
