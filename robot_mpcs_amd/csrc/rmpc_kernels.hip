@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
     double tv, lv;
     if (first) {
       tv = g > kTMin ? g : kTMin;
-      lv = mu / tv;
+      lv = mu * frcp(tv);
     } else {
       const double dtv = gdz + (gold - tcv);
       const double dlv = (mu - tcv * lcv - lcv * dtv) * frcp(tcv);
@@ -458,9 +458,10 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
         if (wi != 0.0) {
           const double cN = (double)M.N * wi;
           if (!(h > 0.0)) bad = 1;
-          f += cN / h;
-          gf[j] += -cN / (h * h) * sg;
-          const double c2 = 2.0 * cN / (h * h * h);
+          const double ih = frcp(h);
+          f += cN * ih;
+          gf[j] += -cN * (ih * ih) * sg;
+          const double c2 = 2.0 * cN * (ih * ih * ih);
           if (j < NQ) Qqq[j < NQ ? j : 0][j < NQ ? j : 0] += c2;
           else Dg[j] += c2;
         }
@@ -611,9 +612,10 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
         if (wi != 0.0) {
           const double cN = (double)M.N * wi;
           if (!(h > 0.0)) bad = 1;
-          f += cN / h;
-          const double c1 = -cN / (h * h), c2 = 2.0 * cN / (h * h * h);
-          cw = cN / (h * h);
+          const double ih = frcp(h);
+          f += cN * ih;
+          const double c1 = -cN * (ih * ih), c2 = 2.0 * cN * (ih * ih * ih);
+          cw = cN * (ih * ih);
 #pragma unroll
           for (int a = 0; a < NQ; a++) {
             gf[a] += c1 * gq[a];
@@ -1430,11 +1432,14 @@ __global__ __launch_bounds__(256) void k_step(const DevModel M, const DevTables 
   double ap = 1.0, ad = 1.0;
   auto row = [&](int i, double gdz, double g, double tv, double lv) __attribute__((always_inline)) {
     const double dt = gdz + (g - tv);
-    const double dl = (mu - tv * lv - lv * dt) / tv;
+    const double itv = frcp(tv);
+    const double dl = (mu - tv * lv - lv * dt) * itv;   // (same expression as in k_sweep's row_core)
     (void)i;  // the steps themselves are not stored: k_sweep recomputes them from the same inputs
-    if (dt < 0) ap = fmin(ap, -kTau * tv / dt);
-    if (dl < 0) ad = fmin(ad, -kTau * lv / dl);
-    gphi -= mu * dt / tv;
+    // ratio tests with Newton reciprocals (the quotient of a non-negative step is discarded by the select)
+    const double rp = -kTau * tv * frcp(dt), rd = -kTau * lv * frcp(dl);
+    ap = (dt < 0 && rp < ap) ? rp : ap;
+    ad = (dl < 0 && rd < ad) ? rd : ad;
+    gphi -= mu * dt * itv;
   };
   // FK rows
   for (int r = 0; r < T.nfkrows; r++) {

@@ -183,8 +183,7 @@ struct Kin {
         }
       }
     } else {
-      c = cos(q[2]);
-      s = sin(q[2]);
+      sincos(q[2], &s, &c);
       qx = q[0];
       qy = q[1];
 #pragma unroll
@@ -249,7 +248,9 @@ struct Kin {
     for (int i = 0; i < 9; i++) R[i] = r[i];
   }
   __device__ __forceinline__ static void rodrigues(const double *k, double th, double (&R)[9]) {
-    double cs = cos(th), sn = sin(th), v = 1.0 - cs;
+    double cs, sn;
+    sincos(th, &sn, &cs);   // one range reduction for both
+    const double v = 1.0 - cs;
     R[0] = cs + k[0] * k[0] * v;        R[1] = k[0] * k[1] * v - k[2] * sn; R[2] = k[0] * k[2] * v + k[1] * sn;
     R[3] = k[1] * k[0] * v + k[2] * sn; R[4] = cs + k[1] * k[1] * v;        R[5] = k[1] * k[2] * v - k[0] * sn;
     R[6] = k[2] * k[0] * v - k[1] * sn; R[7] = k[2] * k[1] * v + k[0] * sn; R[8] = cs + k[2] * k[2] * v;
@@ -295,12 +296,14 @@ __device__ __forceinline__ void diffdrive_step(const double dt, const double (&z
   }
 #pragma unroll 1
   for (int it = 0; it < kErkNodes; it++) {
-    const double c1 = cos(r[2]), s1 = sin(r[2]);
+    double c1, s1;
+    sincos(r[2], &s1, &c1);
     const double k1[5] = {c1 * r[3], s1 * r[3], r[4], u0, u1};
     double rm[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) rm[i] = r[i] + 0.5 * h * k1[i];
-    const double c2 = cos(rm[2]), s2 = sin(rm[2]);
+    double c2, s2;
+    sincos(rm[2], &s2, &c2);
     const double k2[5] = {c2 * rm[3], s2 * rm[3], rm[4], u0, u1};
     if (want) {
       // fx at (r) and (rm): nonzeros (0,2) (0,3) (1,2) (1,3) (2,4)
