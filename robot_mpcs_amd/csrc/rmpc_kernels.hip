@@ -88,6 +88,9 @@ struct Ws {
 };
 
 #define IDX(slot, k, b) (((size_t)(slot) * W.N + (size_t)(k)) * W.Bp + (size_t)(b))
+// the same with the lane's (stage, instance) offset precomputed (k_sweep / k_step): uniform slot base + 32-bit lane offset
+#define IDXL(slot) ((size_t)(slot) * SS + loff)
+#define IDXL1(slot) ((size_t)(slot) * SS + loff1)
 
 // ===========================================================================
 // pack / unpack: instance-major ABI layout <-> batch-minor SoA (LDS transpose)
@@ -292,6 +295,9 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
   const int b = W.act_idx[li];
   if (W.status[b] != ST_ACTIVE) return;
   const int N = M.N;
+  // element offset of this lane inside a slot (32-bit, so that accesses become uniform base + lane offset) and slot size
+  const unsigned loff = (unsigned)k * (unsigned)W.Bp + (unsigned)b;
+  const size_t SS = (size_t)N * W.Bp;
   const int cur = W.cur[b], nxt = cur ^ 1;
   const double *__restrict__ zc = W.z[cur];
   const double *__restrict__ tc = W.t[cur];
@@ -328,19 +334,20 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
   double zo[NV], dzo[NV];   // current iterate and step of this stage (the row steps are recomputed from them)
   {
 #pragma unroll
-    for (int j = 0; j < NV; j++) { zo[j] = zc[IDX(j, k, b)]; dzo[j] = dzp[IDX(j, k, b)]; }
+    for (int j = 0; j < NV; j++) { zo[j] = zc[IDXL(j)]; dzo[j] = dzp[IDXL(j)]; }
     const int k1 = k < N - 1 ? k + 1 : k;  // clamped: loads stay unconditional
+    const unsigned loff1 = (unsigned)k1 * (unsigned)W.Bp + (unsigned)b;
     double x1[NX], dx1[NX], n0[NX], n0n[NX], n1[NX], n1n[NX];
 #pragma unroll
     for (int j = 0; j < NX; j++) {
-      x1[j] = zc[IDX(j, k1, b)]; dx1[j] = dzp[IDX(j, k1, b)];
-      n0[j] = nc[IDX(j, k, b)];  n0n[j] = nup[IDX(j, k, b)];
-      n1[j] = nc[IDX(j, k1, b)]; n1n[j] = nup[IDX(j, k1, b)];
+      x1[j] = zc[IDXL1(j)]; dx1[j] = dzp[IDXL1(j)];
+      n0[j] = nc[IDXL(j)];  n0n[j] = nup[IDXL(j)];
+      n1[j] = nc[IDXL1(j)]; n1n[j] = nup[IDXL1(j)];
     }
 #pragma unroll
     for (int j = 0; j < NV; j++) {
       z[j] = nostep ? zo[j] : zo[j] + alpha * dzo[j];
-      zn[IDX(j, k, b)] = z[j];
+      zn[IDXL(j)] = z[j];
     }
 #pragma unroll
     for (int j = 0; j < NX; j++) {
@@ -350,10 +357,10 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
       if (!first && k < N - 1) w = nostep ? n1[j] : n1[j] + alpha * (n1n[j] - n1[j]);
       nuk[j] = v;
       nun[j] = w;
-      nn[IDX(j, k, b)] = v;
+      nn[IDXL(j)] = v;
     }
   }
-  auto P = [&](int off) __attribute__((always_inline)) -> double { return pp[IDX(off, k, b)]; };
+  auto P = [&](int off) __attribute__((always_inline)) -> double { return pp[IDXL(off)]; };
 
   // ---- accumulators --------------------------------------------------------
   double gf[NV], q0[NV], q1[NV], rs[NV], Dg[NV], cs[NV];
@@ -410,8 +417,8 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
       tv = tcv + am * dtv;
       lv = lcv + dm * dlv;
     }
-    tn[IDX(i, k, b)] = tv;
-    ln[IDX(i, k, b)] = lv;
+    tn[IDXL(i)] = tv;
+    ln[IDXL(i)] = lv;
     const double rg = g - tv;
     theta += fabs(rg);
     if (!(tv > 0.0)) bad = 1;   // (cannot happen: fraction to the boundary; keeps the product's sign meaningful)
@@ -440,9 +447,9 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
       const int i = T.v_row[j][u];
       const int ii = i >= 0 ? i : 0;
       const int po = T.v_poff[j][u];
-      tcv[u] = tc[IDX(ii, k, b)];
-      lcv[u] = lc[IDX(ii, k, b)];
-      const double pl = pp[IDX(po >= 0 ? po : 0, k, b)];
+      tcv[u] = tc[IDXL(ii)];
+      lcv[u] = lc[IDXL(ii)];
+      const double pl = pp[IDXL(po >= 0 ? po : 0)];
       lim[u] = po >= 0 ? pl : T.v_val[j][u];
     }
 #pragma unroll
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
       }
       double g = h;
       if constexpr (NS > 0) { if (soft) g += sl; }
-      if (T.v_poff[j][u] >= 0) grn[IDX(i, k, b)] = g;  // general rows keep their value for k_step
+      if (T.v_poff[j][u] >= 0) grn[IDXL(i)] = g;  // general rows keep their value for k_step
       // the same row at the current iterate (what k_step read back or recomputed)
       double gold = neutral ? 1.0 : sg * (zo[j] - lim[u]);
       double gdz = sg * dzo[j];
@@ -514,7 +521,7 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
     if constexpr (NS > 0) rec[C::R_CS + j] = cs[j];
     rec[C::R_Q0 + j] = gf[j] + q0[j];
     rec[C::R_Q1 + j] = q1[j];
-    W.gfa[IDX(j, k, b)] = gf[j];
+    W.gfa[IDXL(j)] = gf[j];
   };
   constexpr bool CHAIN = (C::ROBOT == RMPC_ROBOT_CHAIN);
   // The arm: velocity and input variables first, so that their accumulators are dead before the kinematics
@@ -558,12 +565,12 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
       const int i = T.fk_row[r], kind = T.fk_kind[r], ob = T.fk_obst[r], mi = T.fk_mod[r];
       // requests first, arithmetic after
       const int fi = T.fk_idx[r];
-      const double tcv = tc[IDX(i, k, b)], lcv = lc[IDX(i, k, b)], gold = gro[IDX(i, k, b)];
+      const double tcv = tc[IDXL(i)], lcv = lc[IDXL(i)], gold = gro[IDXL(i)];
       double gdz = 0.0;
       {
         double jo[NQ];
 #pragma unroll
-        for (int a = 0; a < NQ; a++) jo[a] = jqo[IDX(fi * NQ + a, k, b)];
+        for (int a = 0; a < NQ; a++) jo[a] = jqo[IDXL(fi * NQ + a)];
 #pragma unroll
         for (int a = 0; a < NQ; a++) gdz += jo[a] * dzo[a];
         if constexpr (NS > 0) gdz += dzo[NX];
@@ -626,9 +633,9 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
       }
       double g = h;
       if constexpr (NS > 0) g += sl;  // softened rows (intended InequalityManager.py:29-32)
-      grn[IDX(i, k, b)] = g;
+      grn[IDXL(i)] = g;
 #pragma unroll
-      for (int a = 0; a < NQ; a++) jqn[IDX(fi * NQ + a, k, b)] = gq[a];
+      for (int a = 0; a < NQ; a++) jqn[IDXL(fi * NQ + a)] = gq[a];
       const RowW rw = row_core(i, g, tcv, lcv, gold, gdz);
 #pragma unroll
       for (int a = 0; a < NQ; a++) {
@@ -747,7 +754,7 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
     for (int j = 0; j < NV; j++) {
       rec[C::R_Q0 + j] = gf[j] + q0[j];
       rec[C::R_Q1 + j] = q1[j];
-      W.gfa[IDX(j, k, b)] = gf[j];
+      W.gfa[IDXL(j)] = gf[j];
     }
   }
 
@@ -770,16 +777,16 @@ __global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, c
   rec[C::R_ZERO] = 0.0;
   const double logsum = log(lprod) + 0.6931471805599453094 * (double)lexp;
   if (!isfinite(f) || !isfinite(theta) || !isfinite(logsum)) bad = 1;
-  W.part[IDX(P_F, k, b)] = f;
-  W.part[IDX(P_TH, k, b)] = theta;
-  W.part[IDX(P_LOGS, k, b)] = logsum;
-  W.part[IDX(P_RSTAT, k, b)] = rstat;
-  W.part[IDX(P_REQ, k, b)] = req;
-  W.part[IDX(P_RINEQ, k, b)] = rineq;
-  W.part[IDX(P_RCOMP, k, b)] = rcomp;
-  W.part[IDX(P_SUMC, k, b)] = sumc;
-  W.part[IDX(P_MINC, k, b)] = minc;
-  W.part[IDX(P_BAD, k, b)] = (double)bad;
+  W.part[IDXL(P_F)] = f;
+  W.part[IDXL(P_TH)] = theta;
+  W.part[IDXL(P_LOGS)] = logsum;
+  W.part[IDXL(P_RSTAT)] = rstat;
+  W.part[IDXL(P_REQ)] = req;
+  W.part[IDXL(P_RINEQ)] = rineq;
+  W.part[IDXL(P_RCOMP)] = rcomp;
+  W.part[IDXL(P_SUMC)] = sumc;
+  W.part[IDXL(P_MINC)] = minc;
+  W.part[IDXL(P_BAD)] = (double)bad;
 }
 
 // ===========================================================================
