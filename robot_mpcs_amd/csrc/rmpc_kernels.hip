@@ -1292,7 +1292,8 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
         pn[u] = 0.5 * (a + c);
       }
     }
-    WSYNC();
+    // (no ordering point needed: what is written now -- sP, sPt, sp -- is not read in this phase, and the
+    //  LDS instructions of a wavefront execute in program order)
 #pragma unroll
     for (int u = 0; u < PPL2; u++) {
       const int e = lane + 64 * u;
@@ -1394,7 +1395,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
         dxn = s;
       }
     }
-    WSYNC();
+    // (all lanes have issued their reads of sdx before this store: same wavefront, program order)
     if (k < N - 1 && lane < NX) sdx[lane] = dxn;
     // (next iteration's barrier orders this write before the reads)
   }
