@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--max-iter", type=int, default=0, help="iteration cap per solve (0 = the configs' 200)")
+    ap.add_argument("--ls-max", type=int, default=0, help="step halvings allowed per line search (0 = the default 25)")
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the 8192-instance shard")
     ap.add_argument("--previous-plan", action="store_true", help="warm start from the shifted plan")
     args = ap.parse_args()
@@ -49,6 +50,8 @@ def main():
         d = dict(sc.desc)
         if args.max_iter > 0:
             d["options"] = dict(d["options"], max_iter=args.max_iter)
+        if args.ls_max > 0:
+            d["options"] = dict(d["options"], ls_max=args.ls_max)
         s = Solver(d, max_batch=B)
         ten = dict(goal=t(sc.extra["goal"]), r_body=t(np.full(B, sc.extra["r_body"])),
                    lower_limits=t(np.tile(lim[0], (B, 1))), upper_limits=t(np.tile(lim[1], (B, 1))),
@@ -93,7 +96,7 @@ def main():
     total = sum(f["B"] for f in fleet)
     out = {
         "workload": "BASELINE configs[4], one GPU's shard: " + " + ".join(f"{f['B']} {f['name']}" for f in fleet),
-        "instances": total, "steps": args.steps, "max_iter": args.max_iter or 200,
+        "instances": total, "steps": args.steps, "max_iter": args.max_iter or 200, "ls_max": args.ls_max or 25,
         "warm_start": "previous_plan" if args.previous_plan else "current_state",
         "ms_per_control_step": {"mean": float(times.mean()), "p50": float(np.percentile(times, 50)),
                                 "p90": float(np.percentile(times, 90)), "max": float(times.max())},

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RMPC_VERSION 100 /* 0.1.0 */
+#define RMPC_VERSION 101 /* 0.1.1: rmpc_desc.ls_max */
 
 #define RMPC_MAX_JOINTS 8
 #define RMPC_MAX_LINKS 8
@@ -100,6 +100,9 @@ typedef struct rmpc_desc {
   double mu0;
   int32_t acc_iters;    /* acceptable termination: consecutive stagnant feasible iterations (0 = off, default 8) */
   double acc_obj_tol;   /* ... relative objective change (default 1e-8) */
+  int32_t ls_max;       /* step halvings allowed in one line search (default 25); an instance that exhausts them
+                           stops with exitflag -8 and its current iterate.  Small values bound the number of passes
+                           of a real-time solve (examples/fleet_loop.py) */
 } rmpc_desc;
 
 typedef struct rmpc_handle rmpc_handle;

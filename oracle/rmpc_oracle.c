@@ -907,7 +907,7 @@ int orc_solve(const orc_desc *d, const double *xinit, const double *x0, const do
       double phi0 = obj - mu * logsum + rho * theta;
       alpha = ap;
       accepted = 0;
-      const int ls_cap = use_curv ? ORC_LS_CURV - 1 : ORC_LS_MAX;
+      const int ls_cap = use_curv ? ORC_LS_CURV - 1 : (d->ls_max > 0 ? d->ls_max : ORC_LS_MAX);
       for (ls = 0; ls <= ls_cap; ls++) {
         for (size_t i = 0; i < (size_t)N * nv; i++) w->zt[i] = w->z[i] + alpha * w->dz[i];
         for (size_t i = 0; i < (size_t)N * m; i++) w->tt[i] = w->t[i] + alpha * w->dtt[i];

@@ -96,6 +96,7 @@ typedef struct orc_desc {
   double mu0;
   int32_t acc_iters;
   double acc_obj_tol;
+  int32_t ls_max; /* halvings allowed in one line search (<= 0: ORC_LS_MAX) */
 } orc_desc;
 
 /* Per-stage model evaluation (dense).  All matrices row-major.

@@ -48,7 +48,7 @@ class RmpcDesc(C.Structure):
         ("max_iter", C.c_int32),
         ("tol_stat", C.c_double), ("tol_eq", C.c_double), ("tol_ineq", C.c_double), ("tol_comp", C.c_double),
         ("mu0", C.c_double),
-        ("acc_iters", C.c_int32), ("acc_obj_tol", C.c_double),
+        ("acc_iters", C.c_int32), ("acc_obj_tol", C.c_double), ("ls_max", C.c_int32),
     ]
 
 
@@ -176,6 +176,7 @@ def make_desc(d: dict, device: int = 0) -> RmpcDesc:
     o.tol_ineq = float(opt.get("tol_ineq", 1e-8)); o.tol_comp = float(opt.get("tol_comp", 1e-6))
     o.mu0 = float(opt.get("mu0", 1.0))
     o.acc_iters = int(opt.get("acc_iters", 8)); o.acc_obj_tol = float(opt.get("acc_obj_tol", 1e-8))
+    o.ls_max = int(opt.get("ls_max", 25))
     return o
 
 

@@ -922,7 +922,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     const int usedc = W.usedc[b];
     if (!ok) {
       ls++;
-      if (ls > (usedc ? kLsCurv - 1 : kLsMax)) {
+      if (ls > (usedc ? kLsCurv - 1 : M.ls_max)) {
         if (usedc) {
           // the curvature step failed its line search: recompute this iteration's step with
           // the Gauss-Newton blocks (null pass next); latch after repeated failures
@@ -1903,6 +1903,7 @@ static int build_model(const rmpc_desc &d, DevModel &M, std::string &err) {
   M.mu0 = d.mu0 > 0 ? d.mu0 : 1.0;
   M.acc_iters = d.acc_iters < 0 ? 0 : d.acc_iters;
   M.acc_obj_tol = d.acc_obj_tol > 0 ? d.acc_obj_tol : 1e-8;
+  M.ls_max = d.ls_max > 0 ? d.ls_max : kLsMax;
   // exact curvature of the distance rows: holonomic chain, no slack, n <= 3 and every frame a
   // distance row refers to moves affinely with q (prismatic joints, or revolute at the frame itself)
   auto affine = [&](int f) {

@@ -55,6 +55,7 @@ struct DevModel {
   int use_curv;      // exact curvature of the distance rows (affine kinematics, no slack, n <= 3)
   int acc_iters;     // acceptable termination window (0 = off)
   double acc_obj_tol;
+  int ls_max;        // step halvings allowed in one line search
 };
 
 // Row tables that are too large for the kernel argument live in device memory; they are

@@ -52,6 +52,7 @@ DEFAULT_OPTIONS = {
     "mu0": 1.0,
     "acc_iters": 8,       # acceptable termination window (0 disables)
     "acc_obj_tol": 1e-8,  # relative objective change counted as stagnation
+    "ls_max": 25,         # step halvings allowed in one line search (exitflag -8 beyond)
 }
 
 

@@ -202,6 +202,21 @@ def test_edge_cases(rt):
     s.close()
 
 
+def test_line_search_cap_matches_oracle(rt):
+    """ls_max (rmpc_desc.ls_max): instances that exhaust their halvings stop with -8 on both sides."""
+    sc = rt["make_scenario"]("cfg3", B=256, seed=12)
+    d = dict(sc.desc)
+    d["options"] = dict(d["options"], ls_max=1, max_iter=12)
+    cpu = rt["Oracle"](d).solve_batch(sc.xinit, sc.x0, sc.params)
+    s = rt["Solver"](d, max_batch=256)
+    gpu = s.solve(sc.xinit, sc.x0, sc.params)
+    s.close()
+    assert np.array_equal(gpu["exitflag"], cpu["exitflag"])
+    assert (cpu["exitflag"] == -8).any() or (cpu["exitflag"] == 0).any()   # the caps do bite
+    ok = np.abs(gpu["z"] - cpu["z"]).reshape(256, -1).max(axis=1) <= TOL * np.maximum(1.0, np.abs(cpu["z"]).reshape(256, -1).max(axis=1))
+    assert ok.mean() >= 0.98
+
+
 def test_iteration_cap_returns_usable_plan(rt):
     sc = rt["make_scenario"]("cfg2", B=32, seed=3)
     d = dict(sc.desc); d["options"] = dict(d["options"], max_iter=4)
