@@ -77,6 +77,21 @@ def test_survivor_migration_is_transparent(rt, name, B, seed):
     _check_plan(gpu, cpu, sc.desc["nx"] + sc.desc["ns"])
 
 
+def test_handle_reuse_after_migration(rt):
+    """A handle that has just run a migrating batch solves a small batch exactly like a fresh handle."""
+    big = rt["make_scenario"]("cfg2", B=2048, seed=21)
+    small = rt["make_scenario"]("cfg2", B=100, seed=22)
+    s = rt["Solver"](big.desc, max_batch=2048)
+    s.solve(big.xinit, big.x0, big.params)
+    a = s.solve(small.xinit, small.x0, small.params)
+    s.close()
+    f = rt["Solver"](small.desc, max_batch=100)
+    b = f.solve(small.xinit, small.x0, small.params)
+    f.close()
+    for key in ("z", "exitflag", "iters", "obj", "kkt"):
+        assert np.array_equal(a[key], b[key]), key
+
+
 @pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "boxer", "pointRobot"])
 def test_solve_matches_golden_vectors(rt, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
