@@ -497,6 +497,7 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
 #define ORC_TMIN 1e-2      /* slack push at initialisation */
 #define ORC_TAU 0.995      /* fraction to the boundary */
 #define ORC_LS_MAX 25      /* max halvings in the line search */
+#define ORC_LS_GROW 1      /* step-length memory: a line search starts this many halvings above the last accepted one */
 #define ORC_ARMIJO 1e-4
 #define ORC_MU_DIVERGED 1e12
 #define ORC_CURV_MU 1e-2    /* curvature terms only once the barrier parameter is this small */
@@ -778,6 +779,7 @@ int orc_solve(const orc_desc *d, const double *xinit, const double *x0, const do
   int exitflag = 0, it = 0;
   const int curv_ok = model_uses_curvature(d);
   int gn_sticky = 0, curv_fail = 0, stall = 0;
+  int ls_start = 0; /* step-length memory: halvings the next Gauss-Newton line search starts from */
   double obj_prev = 0.0;
   int ev = eval_all(d, w, params);
   if (ev != 0) { exitflag = (ev == ORC_EVAL_BAD_AVOID) ? -7 : -10; goto done; }
@@ -905,10 +907,13 @@ int orc_solve(const orc_desc *d, const double *xinit, const double *x0, const do
       }
       double D = gphi - rho * theta;
       double phi0 = obj - mu * logsum + rho * theta;
-      alpha = ap;
       accepted = 0;
       const int ls_cap = use_curv ? ORC_LS_CURV - 1 : (d->ls_max > 0 ? d->ls_max : ORC_LS_MAX);
-      for (ls = 0; ls <= ls_cap; ls++) {
+      /* step-length memory: a Gauss-Newton line search starts one halving above the one accepted last;
+       * a step with the exact curvature is tried at full length first */
+      const int ls_begin = use_curv ? 0 : ls_start;
+      alpha = ldexp(ap, -ls_begin);
+      for (ls = ls_begin; ls <= ls_cap; ls++) {
         for (size_t i = 0; i < (size_t)N * nv; i++) w->zt[i] = w->z[i] + alpha * w->dz[i];
         for (size_t i = 0; i < (size_t)N * m; i++) w->tt[i] = w->t[i] + alpha * w->dtt[i];
         double ft, tht, lst;
@@ -925,6 +930,7 @@ int orc_solve(const orc_desc *d, const double *xinit, const double *x0, const do
         continue;
       }
       if (accepted && use_curv) curv_fail = 0;
+      if (accepted) ls_start = ls > ORC_LS_GROW ? ls - ORC_LS_GROW : 0;
       break;
     }
     if (fatal) { exitflag = -5; break; }

@@ -46,6 +46,7 @@ namespace rmpc {
 constexpr double kTMin = 1e-2;
 constexpr double kTau = 0.995;
 constexpr int kLsMax = 25;
+constexpr int kLsGrow = 1;         // step-length memory: a line search starts this many halvings above the last accepted one
 constexpr double kArmijo = 1e-4;
 constexpr double kMuDiverged = 1e12;
 constexpr double kCurvMu = 1e-2; // curvature terms only once the barrier parameter is this small
@@ -82,6 +83,7 @@ struct Ws {
   double *res_stat, *res_eq, *res_ineq, *res_comp, *obj;
   int *status, *iters, *ls, *cur, *newstep;
   int *redo, *force_gn, *gn_sticky, *curv_fail, *usedc, *stall;
+  int *ls0, *lsst;                // halvings the current line search started from / the next one starts from
   int *active_hist;               // [max_passes] instances still iterating after each pass
   int *act_idx, *n_act;           // compacted list of the instances still iterating, its length
   int *orig;                      // [Bp] compact workspace only: column -> instance of the caller's batch
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(256) void k_init(Ws W, const double *__restrict__ x
   W.amin_p[b] = (unsigned long long)__double_as_longlong(1.0);
   W.amin_d[b] = (unsigned long long)__double_as_longlong(1.0);
   W.redo[b] = 0; W.force_gn[b] = 0; W.gn_sticky[b] = 0; W.curv_fail[b] = 0; W.usedc[b] = 0; W.stall[b] = 0;
+  W.ls0[b] = 0; W.lsst[b] = 0;
   W.mu[b] = mu0;
   W.rho[b] = 0.0;
   W.phi0[b] = 0.0;
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(64) void k_migrate(const Ws S, const Ws D, int n, i
     D.status[li] = S.status[b]; D.iters[li] = S.iters[b]; D.ls[li] = S.ls[b]; D.newstep[li] = S.newstep[b];
     D.redo[li] = S.redo[b]; D.force_gn[li] = S.force_gn[b]; D.gn_sticky[li] = S.gn_sticky[b];
     D.curv_fail[li] = S.curv_fail[b]; D.usedc[li] = S.usedc[b]; D.stall[li] = S.stall[b];
+    D.ls0[li] = S.ls0[b]; D.lsst[li] = S.lsst[b];
     D.cur[li] = 0;
     D.orig[li] = b;
     D.act_idx[li] = li;
@@ -897,6 +901,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   int status = ST_ACTIVE;
   int iters = W.iters[b];
   const bool redo = (!first) && (W.redo[b] != 0);
+  int lsst = first ? 0 : W.lsst[b];
   if (first) {
     if (badf != 0.0) status = -7;  // inverse-barrier row not strictly feasible at the start
   } else if (redo) {
@@ -906,7 +911,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     const double a0 = __longlong_as_double((long long)W.amin_p[b]);
     int ls = W.ls[b];
     double rho = W.rho[b], phi0 = W.phi0[b], Dd = W.Dd[b];
-    if (ls == 0) {
+    if (ls == W.ls0[b]) {   // first trial of this line search
       const double thc = W.thcur[b];
       if (thc > 1e-13) {
         const double need = gphi / (0.9 * thc);
@@ -943,6 +948,10 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
       return;  // next sweep retries with alpha / 2
     }
     if (usedc && L0) W.curv_fail[b] = 0;
+    // step-length memory: the next Gauss-Newton line search starts one halving above the accepted one (models
+    // whose steps overshoot every iteration -- the unicycle -- otherwise pay a pass per halving per iteration)
+    lsst = ls > kLsGrow ? ls - kLsGrow : 0;
+    if (L0) W.lsst[b] = lsst;
     iters++;
   }
   // ---- accept the trial point ------------------------------------------------------
@@ -952,7 +961,6 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     __builtin_amdgcn_s_waitcnt(0);  // every lane has read the per-instance words before lane 0 rewrites them
     if (L0) {
       W.cur[b] ^= 1;
-      W.ls[b] = 0;
       W.fcur[b] = f;
       W.thcur[b] = th;
       W.logcur[b] = lgs;
@@ -1003,7 +1011,13 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   bool usec = false;
   if constexpr (C::CURV) usec = M.use_curv && !W.gn_sticky[b] && !W.force_gn[b] && (mu <= kCurvMu);
   __builtin_amdgcn_s_waitcnt(0);
-  if (L0) W.force_gn[b] = 0;
+  if (L0) {
+    W.force_gn[b] = 0;
+    // a step with the exact curvature is tried at full length first
+    const int lsb = usec ? 0 : lsst;
+    W.ls[b] = lsb;
+    W.ls0[b] = lsb;
+  }
   const double cwt = usec ? 1.0 : 0.0;  // Cqq is zero-filled when the model does not use it
 
   // ---- LDS images -------------------------------------------------------------------------
@@ -1980,7 +1994,8 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   double **per[] = {&W.mu, &W.rho, &W.phi0, &W.Dd, &W.fcur, &W.thcur, &W.logcur,
                     &W.res_stat, &W.res_eq, &W.res_ineq, &W.res_comp, &W.obj};
   for (auto pp : per) *pp = c.take<double>(Bp);
-  int **peri[] = {&W.status, &W.iters, &W.ls, &W.cur, &W.newstep, &W.redo, &W.force_gn, &W.gn_sticky, &W.curv_fail, &W.usedc, &W.stall};
+  int **peri[] = {&W.status, &W.iters, &W.ls, &W.cur, &W.newstep, &W.redo, &W.force_gn, &W.gn_sticky, &W.curv_fail, &W.usedc, &W.stall,
+                  &W.ls0, &W.lsst};
   for (auto pp : peri) *pp = c.take<int>(Bp);
   W.active_hist = c.take<int>(max_passes + 8);
   W.act_idx = c.take<int>(Bp);
