@@ -45,6 +45,7 @@ namespace rmpc {
 // solver constants (DESIGN.md, section "Algorithm")
 constexpr double kTMin = 1e-2;
 constexpr double kTau = 0.995;
+constexpr int kSweepBlock = 64;     // threads per k_sweep / k_step block: one wavefront, so that small batches spread over all CUs
 constexpr int kLsMax = 25;
 constexpr int kLsGrow = 1;         // step-length memory: a line search starts this many halvings above the last accepted one
 constexpr double kArmijo = 1e-4;
@@ -288,11 +289,11 @@ __device__ __forceinline__ void for_range(F &&fn) {
 //     loops; absent entries load row 0 and are masked -- a branch around a load,
 //     even a wave-uniform one, makes hipcc wait for every element separately).
 template <class C>
-__global__ __launch_bounds__(256, C::SWEEP_WPE) void k_sweep(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
+__global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
                                                const int B, const int first) {
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV;
   const DevTables &T = *Tp;
-  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int gid = blockIdx.x * kSweepBlock + threadIdx.x;
   const int li = gid % W.Bp;   // position in the compacted list of iterating instances
   const int k = gid / W.Bp;    // uniform per wavefront (Bp % 64 == 0)
   if (li >= *W.n_act || k >= M.N) return;
@@ -1424,11 +1425,11 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
 // k_step: slack / multiplier steps and step-length partials, stage parallel
 // ===========================================================================
 template <class C>
-__global__ __launch_bounds__(256) void k_step(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
+__global__ __launch_bounds__(kSweepBlock) void k_step(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
                                               const int B) {
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NV = C::NV;
   const DevTables &T = *Tp;
-  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int gid = blockIdx.x * kSweepBlock + threadIdx.x;
   const int li = gid % W.Bp;
   const int k = gid / W.Bp;
   if (li >= *W.n_act || k >= M.N) return;
@@ -2046,14 +2047,14 @@ static void launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hi
   const int B = ph.B;
   const int lanes = ph.W.Bp * h->M.N;
   if (ph.W.rs != C::RS) { fprintf(stderr, "rmpc: stage-record layout mismatch (%d != %d)\n", ph.W.rs, C::RS); abort(); }
-  if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, ph.W, B, first);
+  if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B, first);
   else if (which == K_RICCATI) {
     if (C::IPB > 1 && B >= kGroupedMin)
       hipLaunchKernelGGL((k_riccati<C, C::IPB>), dim3((B + C::IPB - 1) / C::IPB), dim3(64 * C::IPB), 0, st, h->M, ph.W, B, first, pass);
     const int tail_blocks = (C::IPB == 1 || B < kGroupedMin) ? B : kGroupedMin;
     hipLaunchKernelGGL((k_riccati<C, 1>), dim3(tail_blocks), dim3(64), 0, st, h->M, ph.W, B, first, pass);
   }
-  else hipLaunchKernelGGL((k_step<C>), dim3((lanes + 255) / 256), dim3(256), 0, st, h->M, h->d_T, ph.W, B);
+  else hipLaunchKernelGGL((k_step<C>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B);
 }
 
 static void launch_variant(rmpc_handle *h, const Phase &ph, int first, int pass, hipStream_t st, int which) {
