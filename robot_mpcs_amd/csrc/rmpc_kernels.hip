@@ -104,10 +104,17 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ in, dou
   __shared__ double tile[64][65];
   const int b0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int r = ty; r < 64; r += 4) {
-    int b = b0 + r, c = c0 + tx;
-    tile[r][tx] = (b < B && c < C) ? in[(size_t)b * C + c] : 0.0;
+  // unconditional requests with clamped indices, all issued before the first LDS store (a branch around a
+  // load makes the compiler wait for each element separately)
+  double v[16];
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int r = ty + 4 * u;
+    const int b = b0 + r < B ? b0 + r : B - 1, c = c0 + tx < C ? c0 + tx : C - 1;
+    v[u] = in[(size_t)b * C + c];
   }
+#pragma unroll
+  for (int u = 0; u < 16; u++) tile[ty + 4 * u][tx] = v[u];
   __syncthreads();
   for (int r = ty; r < 64; r += 4) {
     int c = c0 + r, b = b0 + tx;
@@ -155,14 +162,18 @@ __global__ __launch_bounds__(256) void k_unpack(Ws W, double *__restrict__ zout,
   const int C = N * nv;
   const int b0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int r = ty; r < 64; r += 4) {
-    int c = c0 + r, b = b0 + tx;
-    double v = 0.0;
-    if (c < C && b < B) {
-      int k = c / nv, j = c - k * nv;
-      v = W.z[W.cur[b]][IDX(j, k, b)];
+  {
+    const int b = b0 + tx < B ? b0 + tx : B - 1;   // clamped: the requests stay unconditional
+    const double *__restrict__ zb = W.z[W.cur[b]];
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int c = c0 + ty + 4 * u < C ? c0 + ty + 4 * u : C - 1;
+      const int k = c / nv, j = c - k * nv;
+      v[u] = zb[IDX(j, k, b)];
     }
-    tile[r][tx] = v;
+#pragma unroll
+    for (int u = 0; u < 16; u++) tile[ty + 4 * u][tx] = v[u];
   }
   __syncthreads();
   for (int r = ty; r < 64; r += 4) {
