@@ -203,7 +203,23 @@ def main():
                         traffic = json.load(open(tfile)).get(cfg, {}).get(name)
                     except Exception:
                         traffic = None
+                # whole-solve figures with SURVEY.md 8(d)'s formulas: compulsory I/O + one stage workspace each way
+                # per iteration through HBM, and the Riccati + condensing flop count per iteration
+                nx_, nv_, nh_, np_ = d["nx"], nv, int(d.get("nh", out["config"]["nh"])), d["npar"]
+                nu_w = nv_ - nx_
+                it_avg = float(out["solve_stats"]["iters_mean"])
+                io_b = 8 * (nx_ + 2 * N * nv_ + N * np_) + 16
+                ws_b = 16 * N * (nx_ * nv_ + 2 * nx_ + 2 * nv_ + nv_ * (nv_ + 1) // 2 + nh_ + nh_ * nv_)
+                fl_it = N * (7.0 / 3.0 * nx_ ** 3 + 4 * nx_ ** 2 * nu_w + 2 * nx_ * nu_w ** 2 + nu_w ** 3 / 3.0) + 2.0 * N * nh_ * nv_ ** 2
+                solve_level = {
+                    "bytes_per_solve": io_b + it_avg * ws_b, "achieved_GBps": value * (io_b + it_avg * ws_b) / 1e9,
+                    "frac_hbm": value * (io_b + it_avg * ws_b) / 1e9 / HBM_PEAK_GBPS,
+                    "flops_per_iteration": fl_it, "achieved_fp64_TFLOPs": value * it_avg * fl_it / 1e12,
+                    "frac_fp64_vector": value * it_avg * fl_it / 1e12 / 78.6,
+                    "note": "SURVEY.md 8(d): IO + iters_avg * WS bytes and Riccati + condensing flops per solve, times solves/s",
+                }
                 out["roofline"] = {
+                    "solve_level": solve_level,
                     "kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg_per_launch,
