@@ -253,7 +253,25 @@ def main():
             same = bool(np.array_equal(cpu["exitflag"], exitflag[:nb]))
             conv = cpu["exitflag"] == 1
             dmax = float(np.abs(gz[conv] - cpu["z"][conv]).max()) if conv.any() else 0.0
+            # one instance, one thread, cfg1 -- the closest analogue of the reference's own loop
+            # (one FORCES solve per control step on the CPU) -- and the same single solve through the HIP library
+            sc1 = make_scenario("cfg1", B=1, seed=0)
+            o1 = Oracle(sc1.desc)
+            o1.solve_batch(sc1.xinit, sc1.x0, sc1.params, nthreads=1)
+            t1c = time.perf_counter()
+            for _ in range(20):
+                o1.solve_batch(sc1.xinit, sc1.x0, sc1.params, nthreads=1)
+            cpu1_ms = 1e3 * (time.perf_counter() - t1c) / 20
+            s1 = Solver(sc1.desc, max_batch=1, device=local_rank)
+            s1.solve(sc1.xinit, sc1.x0, sc1.params)
+            t1g = time.perf_counter()
+            for _ in range(20):
+                s1.solve(sc1.xinit, sc1.x0, sc1.params)
+            gpu1_ms = 1e3 * (time.perf_counter() - t1g) / 20
+            s1.close()
             out["cpu_baseline"] = {
+                "single_instance_cfg1": {"cpu_port_1_thread_ms": cpu1_ms, "hip_host_entry_ms": gpu1_ms,
+                                         "note": "BASELINE configs[0], one solve per call, host-pointer entry (PCIe included)"},
                 "value": nb / tcpu, "unit": "solves/s", "cores": cores, "kind": "port",
                 "sample": f"{nb} instances of the same workload (rank 0's inputs), one pass, OpenMP over instances",
                 "seconds": tcpu, "exitflags_equal_gpu": same, "max_abs_diff_vs_gpu_plan": dmax,
