@@ -40,5 +40,32 @@ def main():
         print(name, "B", B, "iters", r["iters"].tolist())
 
 
+def closed_loop_trace(name="cfg1", steps=50):
+    """50-step closed loop of the reference example scenario: solve, apply the first
+    control to the model's own ERK2 map, re-initialise with the current state (mpcPlanner.py:229-236)."""
+    sc = make_scenario(name, B=1, seed=0)
+    o = Oracle(sc.desc)
+    nx, nv, N = o.nx, o.nv, o.N
+    x = sc.xinit[0].copy()
+    xs, us, flags = [x.copy()], [], []
+    for _ in range(steps):
+        x0 = np.zeros((N, nv))
+        x0[:, :nx] = x
+        r = o.solve(x, x0.reshape(-1), sc.params[0])
+        u = r["z"][0, nv - o.nu:]
+        x = o.dynamics(x, u)
+        xs.append(x.copy()); us.append(u.copy()); flags.append(r["exitflag"])
+    return sc, np.array(xs), np.array(us), np.array(flags, dtype=np.int32)
+
+
+def main_closed_loop():
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    sc, xs, us, flags = closed_loop_trace()
+    np.savez_compressed(os.path.join(out_dir, "cfg1_closed_loop.npz"), desc=json.dumps(sc.desc), params=sc.params,
+                        xs=xs, us=us, exitflag=flags)
+    print("cfg1 closed loop: final state", xs[-1][:3], "exitflags", np.unique(flags).tolist())
+
+
 if __name__ == "__main__":
     main()
+    main_closed_loop()

@@ -294,3 +294,26 @@ def test_planner_drop_in_closed_loop(rt, tmp_path):
         xn = o.dynamics(np.concatenate([q, qdot]), action)
         q, qdot = xn[:3], xn[3:]
     assert q[0] > 0.25 and abs(action[0] - 1.0) < 1e-5  # accelerating towards the goal at the input limit
+
+
+def test_closed_loop_matches_golden_trace(rt):
+    """50 control steps of the reference example scenario with the HIP solver in the loop (B = 1, plant = the
+    oracle's ERK2 map, current-state initialisation) against the committed oracle trace."""
+    import json
+    g = np.load(os.path.join(GOLDEN, "cfg1_closed_loop.npz"))
+    desc = json.loads(str(g["desc"]))
+    desc["lb"] = [float(v) for v in desc["lb"]]; desc["ub"] = [float(v) for v in desc["ub"]]
+    o = rt["Oracle"](desc)
+    s = rt["Solver"](desc, max_batch=1)
+    nx, nv, N = o.nx, o.nv, o.N
+    x = g["xs"][0].copy()
+    for t in range(g["us"].shape[0]):
+        x0 = np.zeros((1, N, nv))
+        x0[0, :, :nx] = x
+        r = s.solve(x[None], x0, g["params"][:1])
+        assert r["exitflag"][0] == g["exitflag"][t]
+        u = r["z"][0, 0, nv - o.nu:]
+        assert np.abs(u - g["us"][t]).max() <= TOL * max(1.0, np.abs(g["us"][t]).max()), t
+        x = o.dynamics(x, u)
+        assert np.abs(x - g["xs"][t + 1]).max() <= TOL, t
+    s.close()

@@ -171,3 +171,19 @@ def test_golden_fixtures_reproduce_from_oracle(oracle_lib):
         e = o.eval_stage(g["x0"][0, 0], g["params"][0].reshape(o.N, o.npar)[0])
         np.testing.assert_allclose(e["g"], g["stage_g"], atol=1e-13)
         np.testing.assert_allclose(e["H"], g["stage_H"], atol=1e-10)
+
+
+def test_closed_loop_golden_trace_reproduces_from_oracle(oracle_lib):
+    """tests/golden/cfg1_closed_loop.npz (50 control steps of the reference example scenario) is what the
+    oracle-driven loop of tests/golden/make_golden.py computes today."""
+    import importlib.util
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(gdir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(gdir, "cfg1_closed_loop.npz"))
+    _, xs, us, flags = mg.closed_loop_trace()
+    assert np.array_equal(flags, g["exitflag"])
+    np.testing.assert_allclose(xs, g["xs"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(us, g["us"], rtol=0, atol=1e-9)
+    assert xs[-1][0] > xs[0][0] + 2.0   # it does drive towards the goal
