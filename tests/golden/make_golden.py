@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 from oracle.oracle import Oracle  # noqa: E402
 from robot_mpcs_amd.scenarios import make_scenario  # noqa: E402
 
-CASES = [("cfg1", 1, 0), ("cfg2", 8, 21), ("cfg3", 8, 22), ("cfg4", 8, 23), ("boxer", 4, 24), ("pointRobot", 2, 25)]
+CASES = [("cfg1", 1, 0), ("cfg2", 8, 21), ("cfg3", 8, 22), ("cfg4", 8, 23), ("boxer", 4, 24), ("pointRobot", 2, 25), ("panda", 2, 26)]
 
 
 def main():

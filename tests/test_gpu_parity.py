@@ -92,7 +92,7 @@ def test_handle_reuse_after_migration(rt):
         assert np.array_equal(a[key], b[key]), key
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "boxer", "pointRobot"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "boxer", "pointRobot", "panda"])
 def test_solve_matches_golden_vectors(rt, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     desc = json.loads(str(g["desc"]))

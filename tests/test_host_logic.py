@@ -160,7 +160,7 @@ def test_golden_fixtures_reproduce_from_oracle(oracle_lib):
     import json
     from oracle.oracle import Oracle
     gdir = os.path.join(os.path.dirname(__file__), "golden")
-    for name in ("cfg1", "cfg2", "cfg3", "cfg4", "boxer", "pointRobot"):
+    for name in ("cfg1", "cfg2", "cfg3", "cfg4", "boxer", "pointRobot", "panda"):
         g = np.load(os.path.join(gdir, name + ".npz"))
         desc = json.loads(str(g["desc"]))
         desc["lb"] = [float(v) for v in desc["lb"]]; desc["ub"] = [float(v) for v in desc["ub"]]
