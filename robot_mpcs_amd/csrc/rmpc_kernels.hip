@@ -847,19 +847,23 @@ __device__ __forceinline__ void chol_solve(const double (&L)[NW][NW], const doub
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
   } while (0)
 
+// reductions over the LPI consecutive lanes that work on one instance (a whole wavefront or half of one)
+template <int LPI>
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  for (int off = LPI / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+template <int LPI>
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  for (int off = LPI / 2; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
   return v;
 }
+template <int LPI>
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+  for (int off = LPI / 2; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
   return v;
 }
 
@@ -877,18 +881,23 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   if constexpr (C::IPB > 1) {
     if ((IPB > 1) != (nact >= kGroupedMin)) return;
   }
-  const int wv = threadIdx.x >> 6;
-  const int li = blockIdx.x * IPB + wv;
+  // lanes per instance: a whole wavefront, or half of one in the grouped regime of the small models (their
+  // dense blocks have few rows: two instances per wavefront halve the LDS instructions an instance costs, and
+  // LDS instruction throughput is what bounds this kernel when the whole batch iterates)
+  constexpr int LPI = (IPB > 1) ? C::RIC_LPI : 64;
+  constexpr int IPW = 64 / LPI;
+  const int wv = threadIdx.x / LPI;   // instance slot within the block
+  const int li = blockIdx.x * (IPB * IPW) + wv;
   if (li >= nact) return;
   const int b = W.act_idx[li];
   if (W.status[b] != ST_ACTIVE) return;  // uniform: one instance per wavefront
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & (LPI - 1);
   const int N = M.N;
   (void)B;
 
   // ---- reduce the stage partials of the trial point --------------------------------
   double f = 0, th = 0, lgs = 0, rstat = 0, req = 0, rineq = 0, rcomp = 0, sumc = 0, minc = 1e300, badf = 0, gphi = 0;
-  for (int k = lane; k < N; k += 64) {
+  for (int k = lane; k < N; k += LPI) {
     f += W.part[IDX(P_F, k, b)];
     th += W.part[IDX(P_TH, k, b)];
     lgs += W.part[IDX(P_LOGS, k, b)];
@@ -901,10 +910,10 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     badf += W.part[IDX(P_BAD, k, b)];
     gphi += first ? 0.0 : W.gphi[(size_t)k * W.Bp + b];
   }
-  f = wave_sum(f); th = wave_sum(th); lgs = wave_sum(lgs); sumc = wave_sum(sumc); badf = wave_sum(badf);
-  gphi = wave_sum(gphi);
-  rstat = wave_max(rstat); req = wave_max(req); rineq = wave_max(rineq); rcomp = wave_max(rcomp);
-  minc = wave_min(minc);
+  f = wave_sum<LPI>(f); th = wave_sum<LPI>(th); lgs = wave_sum<LPI>(lgs); sumc = wave_sum<LPI>(sumc); badf = wave_sum<LPI>(badf);
+  gphi = wave_sum<LPI>(gphi);
+  rstat = wave_max<LPI>(rstat); req = wave_max<LPI>(req); rineq = wave_max<LPI>(rineq); rcomp = wave_max<LPI>(rcomp);
+  minc = wave_min<LPI>(minc);
 
   // ---- decisions: every lane computes them (identical values), lane 0 stores ---------
   const bool L0 = (lane == 0);
@@ -1037,9 +1046,9 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   // LDS so that it leaves for (and returns from) the instance's gain record KP in one request
   constexpr int NP2 = NX * (NX + 1) / 2;
   constexpr int KPW = NW * NX + NW + NP2 + NX + NX;
-  constexpr int KPL = (KPW + 63) / 64;
+  constexpr int KPL = (KPW + LPI - 1) / LPI;
   constexpr int LDSW = KPW + NX * NX + NX * NV + NV * NV + NV + NX * NV + NX + NX + NW + C::RS;
-  __shared__ double lds[IPB][LDSW];
+  __shared__ double lds[IPB * IPW][LDSW];
   double *const img = lds[wv], *const sK = img, *const skf = sK + NW * NX, *const sPt = skf + NW, *const sp = sPt + NP2,
                *const src = sp + NX, *const sP = img + KPW, *const sAB = sP + NX * NX, *const sQ = sAB + NX * NV,
                *const sq = sQ + NV * NV, *const sT = sq + NV, *const sPc = sT + NX * NV, *const sdx = sPc + NX,
@@ -1059,13 +1068,13 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   const double *const rb = W.R + (size_t)b * N * C::RS;   // stage 0 record of this instance
   const double *const zer = rb + C::R_ZERO;
   constexpr size_t sstr = (size_t)C::RS;                  // stage stride of the records
-  constexpr int EPL = (NV * NV + 63) / 64;   // stage Hessian entries per lane
-  constexpr int TPL = (NX * NV + 63) / 64;   // entries of T = P [A|B] (and of [A|B]) per lane
-  constexpr int RPL = (C::RS + 63) / 64;     // record entries per lane
+  constexpr int EPL = (NV * NV + LPI - 1) / LPI;   // stage Hessian entries per lane
+  constexpr int TPL = (NX * NV + LPI - 1) / LPI;   // entries of T = P [A|B] (and of [A|B]) per lane
+  constexpr int RPL = (C::RS + LPI - 1) / LPI;     // record entries per lane
   int qp[EPL], cp[EPL];                      // record entries a dense-block entry of this lane is made of
 #pragma unroll
   for (int u = 0; u < EPL; u++) {
-    const int e = lane + 64 * u;
+    const int e = lane + LPI * u;
     qp[u] = C::R_ZERO; cp[u] = C::R_ZERO;
     if (e < NV * NV) {
       const int i = e / NV, j = e - i * NV;
@@ -1089,7 +1098,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   if constexpr (DD) {
 #pragma unroll
     for (int u = 0; u < TPL; u++) {
-      const int e = lane + 64 * u;
+      const int e = lane + LPI * u;
       abp[u] = C::R_ZERO; abc[u] = 0.0;
       if (e < NX * NV) {
         const int i = e / NV, j = e - i * NV;
@@ -1109,14 +1118,14 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     if constexpr (DD) {
 #pragma unroll
       for (int u = 0; u < TPL; u++) {
-        const int e = lane + 64 * u;
+        const int e = lane + LPI * u;
         const double v = srec[abp[u]] + abc[u];
         if (e < NX * NV) sAB[e] = v;
       }
     }
   };
 
-  for (int e = lane; e < NX * NX; e += 64) sP[e] = 0.0;
+  for (int e = lane; e < NX * NX; e += LPI) sP[e] = 0.0;
   if (lane < NX) sp[lane] = 0.0;
   bool chol_ok = true;
 
@@ -1125,7 +1134,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   auto fetch_stage = [&](int k) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < RPL; u++) {
-      const int e = lane + 64 * u;
+      const int e = lane + LPI * u;
       recv[u] = rb[(size_t)k * sstr + (e < C::RS ? e : 0)];
     }
   };
@@ -1136,12 +1145,12 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     double kpv[KPL];
 #pragma unroll
     for (int u = 0; u < KPL; u++) {
-      const int e = lane + 64 * u;
+      const int e = lane + LPI * u;
       kpv[u] = img[e < KPW ? e : 0];
     }
 #pragma unroll
     for (int u = 0; u < RPL; u++) {
-      const int e = lane + 64 * u;
+      const int e = lane + LPI * u;
       if (e < C::RS) srec[e] = recv[u];
     }
     if (k > 0) fetch_stage(k - 1);  // travels while this stage is computed
@@ -1150,7 +1159,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
       double *const kp1 = W.KP + ((size_t)b * N + (k + 1)) * W.kps;
 #pragma unroll
       for (int u = 0; u < KPL; u++) {
-        const int e = lane + 64 * u;
+        const int e = lane + LPI * u;
         if (e < KPW) kp1[e] = kpv[u];
       }
     }
@@ -1161,7 +1170,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
       const bool rec_cost = k < N - 1;   // a cost-to-go of stage k+1 exists
 #pragma unroll
       for (int u = 0; u < EPL; u++) {
-        const int e = lane + 64 * u;
+        const int e = lane + LPI * u;
         double v = srec[qp[u]] - cwt * srec[cp[u]];
         if (e < NV * NV) {
           const int i = e / NV, j = e - i * NV;
@@ -1208,7 +1217,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
       // -- fill: dense stage Hessian, gradient, defect (rc of stage N-1: finite, unused), [A|B] -------
 #pragma unroll
       for (int u = 0; u < EPL; u++) {
-        const int e = lane + 64 * u;
+        const int e = lane + LPI * u;
         const double v = srec[qp[u]] - cwt * srec[cp[u]];
         if (e < NV * NV) sQ[e] = v;
       }
@@ -1220,7 +1229,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
       // -- T = P [A|B], Pc = P rc + p ---------------------------------------------------------
 #pragma unroll
       for (int u = 0; u < TPL; u++) {
-        const int e = lane + 64 * u;
+        const int e = lane + LPI * u;
         if (e < NX * NV) {
           const int i = e / NV, j = e - i * NV;
           double s = 0.0;
@@ -1239,7 +1248,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
       // -- Q += [A|B]^T T, q += [A|B]^T Pc ---------------------------------------------------------
 #pragma unroll
       for (int u = 0; u < EPL; u++) {
-        const int e = lane + 64 * u;
+        const int e = lane + LPI * u;
         if (e < NV * NV) {
           const int i = e / NV, j = e - i * NV;
           double s = sQ[e];
@@ -1297,11 +1306,11 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     // -- cost-to-go: P = sym(Qxx + Qxw K), p = qx + Qxw kff ---------------------------------------------
     // entries e < NX*NX are P(i, j); the next NX entries are p(i), written as the same expression with the
     // "column" kff and no transposed partner (a == c, 0.5 (a + a) = a exactly): one instruction stream
-    constexpr int PPL2 = (NX * NX + NX + 63) / 64;
+    constexpr int PPL2 = (NX * NX + NX + LPI - 1) / LPI;
     double pn[PPL2];
 #pragma unroll
     for (int u = 0; u < PPL2; u++) {
-      const int e = lane + 64 * u;
+      const int e = lane + LPI * u;
       pn[u] = 0.0;
       if (e < NX * NX + NX) {
         const bool isP = e < NX * NX;
@@ -1322,7 +1331,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     //  LDS instructions of a wavefront execute in program order)
 #pragma unroll
     for (int u = 0; u < PPL2; u++) {
-      const int e = lane + 64 * u;
+      const int e = lane + LPI * u;
       if (e < NX * NX) {
         sP[e] = pn[u];
         const int i = e / NX, j = e - i * NX;
@@ -1355,7 +1364,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   auto fetch_fwd = [&](int k) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < KPL; u++) {
-      const int e = lane + 64 * u;
+      const int e = lane + LPI * u;
       fv[u] = kpb[(size_t)k * W.kps + (e < KPW ? e : 0)];
     }
   };
@@ -1364,7 +1373,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     if (k > 0) {
 #pragma unroll
       for (int u = 0; u < KPL; u++) {
-        const int e = lane + 64 * u;
+        const int e = lane + LPI * u;
         if (e < KPW) img[e] = fv[u];
       }
     }
@@ -1372,7 +1381,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
       if (k < N - 1) {   // [A|B] of stage k straight from its record (diff-drive only)
 #pragma unroll
         for (int u = 0; u < TPL; u++) {
-          const int e = lane + 64 * u;
+          const int e = lane + LPI * u;
           const double v = rb[(size_t)k * sstr + abp[u]] + abc[u];
           if (e < NX * NV) sAB[e] = v;
         }
@@ -2061,7 +2070,10 @@ static void launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hi
   if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B, first);
   else if (which == K_RICCATI) {
     if (C::IPB > 1 && B >= kGroupedMin)
-      hipLaunchKernelGGL((k_riccati<C, C::IPB>), dim3((B + C::IPB - 1) / C::IPB), dim3(64 * C::IPB), 0, st, h->M, ph.W, B, first, pass);
+    {
+      constexpr int per_block = C::IPB * (64 / C::RIC_LPI);   // instances per block
+      hipLaunchKernelGGL((k_riccati<C, C::IPB>), dim3((B + per_block - 1) / per_block), dim3(64 * C::IPB), 0, st, h->M, ph.W, B, first, pass);
+    }
     const int tail_blocks = (C::IPB == 1 || B < kGroupedMin) ? B : kGroupedMin;
     hipLaunchKernelGGL((k_riccati<C, 1>), dim3(tail_blocks), dim3(64), 0, st, h->M, ph.W, B, first, pass);
   }

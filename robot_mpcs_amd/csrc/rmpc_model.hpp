@@ -118,6 +118,8 @@ struct Cfg {
   // k_riccati: no register cap (94 VGPRs for the point robot) -- at 80 the recursion spills inside its stage
   // loop: -3 % throughput on cfg2, -20 % on cfg3 (measured)
   static constexpr int RIC_WPE = 1;
+  // lanes per instance in the grouped Riccati blocks: half a wavefront for the small models
+  static constexpr int RIC_LPI = (NX + NS_ + NU <= 16) ? 32 : 64;
   // Stage record handed from k_sweep to k_riccati, one per (instance, stage), instance-major:
   //   Qqq (upper triangle) | Cqq | Dg (variables >= NQ) | cs (softened models) | q0 | q1 | rc | A5 B5 (diff-drive)
   // A lane of k_sweep scatters its stage's entries into the record; a wavefront of k_riccati then
