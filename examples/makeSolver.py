@@ -12,6 +12,7 @@ involved: the HIP library is model-generic and built once by
 ``__graft_entry__.build()``.
 """
 import os
+import re
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -30,8 +31,21 @@ def main(setup_file: str):
     return target
 
 
+def setup_file_from_argv(arg: str) -> str:
+    """The reference's argv contract (``examples/makeSolver.py:26-29``): the robot type is whatever stands
+    between the last '/' and 'Mpc' -- ``re.findall('\\/(\\S*)M', arg)[0]`` -- and the file read is
+    ``config/<type>Mpc.yaml``.  ``python makeSolver.py config/pointRobotMpc.yaml`` therefore behaves as there;
+    any other existing path (absolute, or a config outside ``config/``) is taken as is."""
+    found = re.findall(r'\/(\S*)M', arg)
+    if found:
+        candidate = 'config/' + str(found[0]) + "Mpc.yaml"
+        if os.path.isfile(os.path.join(HERE, candidate)) and not os.path.isabs(arg):
+            return candidate
+    return arg
+
+
 if __name__ == "__main__":
     if len(sys.argv) < 2:
         print("Please provide a config file for solver generation.")
         sys.exit(1)
-    main(sys.argv[1])
+    main(setup_file_from_argv(sys.argv[1]))

@@ -108,6 +108,10 @@ typedef struct rmpc_desc {
 typedef struct rmpc_handle rmpc_handle;
 
 int rmpc_version(void);
+/* sha256 (first 16 hex digits) of the sources this binary was built from (csrc/rmpc_kernels.hip,
+ * csrc/rmpc_model.hpp, include/rmpc.h), embedded by __graft_entry__.build(); the Python binding
+ * refuses a library whose hash differs from the sources next to it. */
+const char *rmpc_source_hash(void);
 const char *rmpc_last_error(void);
 int rmpc_desc_size(void);
 
@@ -123,9 +127,11 @@ int rmpc_solve_batch(rmpc_handle *h, int B, const double *xinit, const double *x
                      const double *params, double *z_out, int32_t *exitflag,
                      int32_t *iters, double *kkt_res, double *obj);
 
-/* Same, device pointers (e.g. torch tensor data_ptr()).  All work is enqueued
- * on `stream` (a hipStream_t; NULL = the handle's own stream); returns after
- * the final kernel is enqueued and the iteration loop has drained. */
+/* Same, device pointers (e.g. torch tensor data_ptr()).  All work is enqueued on `stream`
+ * (a hipStream_t; NULL = the legacy null stream, i.e. ordered with the caller's default-stream
+ * work such as the torch ops that produced the inputs).  Returns when the iteration loop has
+ * drained and the final kernel (the one that writes d_z_out ... d_obj) is ENQUEUED: the outputs
+ * are valid for later work on the same stream, or for the host after a stream synchronize. */
 int rmpc_solve_batch_device(rmpc_handle *h, int B, const double *d_xinit,
                             const double *d_x0, const double *d_params,
                             double *d_z_out, int32_t *d_exitflag, int32_t *d_iters,

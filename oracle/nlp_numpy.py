@@ -235,3 +235,64 @@ class HorizonNLP:
             options={"maxiter": maxiter, "ftol": ftol},
         )
         return self.unpack(res.x), res
+
+
+# ---------------------------------------------------------------------------
+# structured finite-difference Jacobians (stage-wise), so that a full-horizon scipy solve is
+# affordable without borrowing any derivative from rmpc_oracle.c
+# ---------------------------------------------------------------------------
+class StructuredNLP(HorizonNLP):
+    """HorizonNLP with dense Jacobians assembled from per-stage central differences of the numpy
+    stage functions (each stage depends on its own nvar variables, the dynamics couple neighbours)."""
+
+    EPS = 1e-6
+
+    def _cols(self, k):
+        """decision-vector columns of stage k's variables (stage 0: only s, u are free)"""
+        if k == 0:
+            return np.arange(self.nx, self.nv), np.arange(0, self.nw)
+        off = self.nw + (k - 1) * self.nv
+        return np.arange(0, self.nv), np.arange(off, off + self.nv)
+
+    def grad(self, y):
+        Z = self.unpack(y)
+        g = np.zeros_like(y)
+        for k in range(self.N):
+            loc, col = self._cols(k)
+            G = fd_grad(lambda zz: stage_cost(self.d, zz, self.P[k], fixed_state=(k == 0)), Z[k], self.EPS)[0]
+            g[col] = G[loc]
+        return g
+
+    def eq_jac(self, y):
+        Z = self.unpack(y)
+        J = np.zeros(((self.N - 1) * self.nx, y.size))
+        for k in range(self.N - 1):
+            loc, col = self._cols(k)
+            D = fd_grad(lambda zz: dynamics(self.d, zz[: self.nx], zz[self.nx + self.ns:]), Z[k], self.EPS)
+            J[k * self.nx:(k + 1) * self.nx][:, col] = D[:, loc]
+            _, coln = self._cols(k + 1)
+            J[k * self.nx:(k + 1) * self.nx, coln[: self.nx]] -= np.eye(self.nx)
+        return J
+
+    def ineq_jac(self, y):
+        Z = self.unpack(y)
+        rows = []
+        for k in range(self.N):
+            loc, col = self._cols(k)
+            D = fd_grad(lambda zz: stage_ineq(self.d, zz, self.P[k], with_bounds=False, fixed_state=(k == 0)),
+                        Z[k], self.EPS)
+            Jk = np.zeros((D.shape[0], y.size))
+            Jk[:, col] = D[:, loc]
+            rows.append(Jk)
+        return np.vstack(rows)
+
+    def solve_slsqp(self, Z0, maxiter=400, ftol=1e-13):
+        from scipy.optimize import minimize
+        y0 = self.pack(np.asarray(Z0, dtype=float).reshape(self.N, self.nv))
+        res = minimize(
+            self.objective, y0, jac=self.grad, method="SLSQP", bounds=self.bounds(),
+            constraints=[{"type": "eq", "fun": self.eq, "jac": self.eq_jac},
+                         {"type": "ineq", "fun": self.ineq, "jac": self.ineq_jac}],
+            options={"maxiter": maxiter, "ftol": ftol},
+        )
+        return self.unpack(res.x), res

@@ -69,13 +69,33 @@ class RmpcScene(C.Structure):
 
 # every symbol include/rmpc.h declares
 EXPORTED_SYMBOLS = [
-    "rmpc_version", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
+    "rmpc_version", "rmpc_source_hash", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
     "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_profiling", "rmpc_get_profile",
     "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep",
     "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_advance_device", "rmpc_free_space_device",
 ]
 
 _lib = None
+
+
+def _source_hash():
+    """Hash of the sources next to the library (None when they are not shipped alongside)."""
+    import hashlib
+    root = os.path.dirname(_HERE)
+    paths = [os.path.join(_HERE, "csrc", "rmpc_kernels.hip"), os.path.join(_HERE, "csrc", "rmpc_model.hpp"),
+             os.path.join(root, "include", "rmpc.h")]
+    if not all(os.path.exists(p) for p in paths):
+        return None
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def source_hash() -> str:
+    """Hash embedded in the loaded library (``rmpc_source_hash()``)."""
+    return load_library().rmpc_source_hash().decode()
 
 
 def load_library(path: str = LIB_PATH):
@@ -97,6 +117,7 @@ def load_library(path: str = LIB_PATH):
     L = C.CDLL(path)
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     L.rmpc_version.restype = C.c_int
+    L.rmpc_source_hash.restype = C.c_char_p
     L.rmpc_last_error.restype = C.c_char_p
     L.rmpc_desc_size.restype = C.c_int
     L.rmpc_create.restype = C.c_int
@@ -129,6 +150,10 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_free_space_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     if L.rmpc_desc_size() != C.sizeof(RmpcDesc):
         raise RmpcError("rmpc_desc layout mismatch between _lib.py and librmpc_hip.so")
+    want = _source_hash()
+    if want is not None and L.rmpc_source_hash().decode() != want:
+        raise RmpcError("librmpc_hip.so is stale: built from other sources than the ones next to it "
+                        f"({L.rmpc_source_hash().decode()} != {want}); run __graft_entry__.build()")
     _lib = L
     return L
 
@@ -184,6 +209,20 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def _stream_arg(stream):
+    """``stream``: an int / hipStream_t handle, or None = the stream the caller's torch ops run on
+    (``torch.cuda.current_stream()``; the legacy null stream when torch is absent), so that the solver's
+    kernels are ordered after the ops that produced the inputs and before the ops that read the outputs."""
+    if stream is None:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                stream = torch.cuda.current_stream().cuda_stream
+        except ImportError:
+            stream = 0
+    return C.c_void_p(int(stream or 0))
+
+
 def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
 
@@ -195,7 +234,7 @@ def free_space_decomposition_device(points, seeds, planes_out, max_radius: float
     L = load_library()
     B, P = int(points.shape[0]), int(points.shape[1])
     N, K = int(seeds.shape[1]), int(planes_out.shape[2])
-    st = C.c_void_p(int(stream)) if stream else C.c_void_p(0)
+    st = _stream_arg(stream)
     rc = L.rmpc_free_space_device(B, N, P, K, float(max_radius), C.c_void_p(points.data_ptr()),
                                   C.c_void_p(seeds.data_ptr()), C.c_void_p(planes_out.data_ptr()), st)
     if rc != 0:
@@ -254,7 +293,7 @@ class Solver:
     # -- device buffers (anything exposing data_ptr(), e.g. torch tensors) ---------
     def solve_device(self, B, xinit, x0, params, z_out, exitflag, iters, kkt, obj, stream=None):
         ptr = lambda t: C.c_void_p(t.data_ptr())
-        st = C.c_void_p(int(stream)) if stream else C.c_void_p(0)
+        st = _stream_arg(stream)
         rc = self._L.rmpc_solve_batch_device(self._h, int(B), ptr(xinit), ptr(x0), ptr(params), ptr(z_out),
                                              ptr(exitflag), ptr(iters), ptr(kkt), ptr(obj), st)
         self._check(rc, "rmpc_solve_batch_device")
@@ -277,19 +316,19 @@ class Solver:
         return s
 
     def pack_scene_device(self, B, scene: RmpcScene, params_out, stream=None):
-        st = C.c_void_p(int(stream)) if stream else C.c_void_p(0)
+        st = _stream_arg(stream)
         rc = self._L.rmpc_pack_scene_device(self._h, int(B), C.byref(scene), C.c_void_p(params_out.data_ptr()), st)
         self._check(rc, "rmpc_pack_scene_device")
 
     def solve_scene_device(self, B, scene: RmpcScene, xinit, x0, z_out, exitflag, iters, kkt, obj, stream=None):
         ptr = lambda t: C.c_void_p(t.data_ptr())
-        st = C.c_void_p(int(stream)) if stream else C.c_void_p(0)
+        st = _stream_arg(stream)
         rc = self._L.rmpc_solve_batch_scene_device(self._h, int(B), C.byref(scene), ptr(xinit), ptr(x0), ptr(z_out),
                                                    ptr(exitflag), ptr(iters), ptr(kkt), ptr(obj), st)
         self._check(rc, "rmpc_solve_batch_scene_device")
 
     def advance_device(self, B, z_prev, xinit, x0, previous_plan: bool, stream=None):
-        st = C.c_void_p(int(stream)) if stream else C.c_void_p(0)
+        st = _stream_arg(stream)
         rc = self._L.rmpc_advance_device(self._h, int(B), C.c_void_p(z_prev.data_ptr()), C.c_void_p(xinit.data_ptr()),
                                          C.c_void_p(x0.data_ptr()), 1 if previous_plan else 0, st)
         self._check(rc, "rmpc_advance_device")

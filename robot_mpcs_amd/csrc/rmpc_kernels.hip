@@ -890,7 +890,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   const int li = blockIdx.x * (IPB * IPW) + wv;
   if (li >= nact) return;
   const int b = W.act_idx[li];
-  if (W.status[b] != ST_ACTIVE) return;  // uniform: one instance per wavefront
+  if (W.status[b] != ST_ACTIVE) return;  // uniform over the lanes of an instance (whole wavefront, or one half in the grouped regime)
   const int lane = threadIdx.x & (LPI - 1);
   const int N = M.N;
   (void)B;
@@ -1583,6 +1583,10 @@ __global__ __launch_bounds__(256) void k_scene(const SceneDev S, const SceneOff 
       }
     } else if (S.obst) {
       for (int j = 0; j < 4 * O.nobst; j++) put(O.obst + j, S.obst[(size_t)b * 4 * O.nobst + j]);
+    } else {
+      // no obstacles given: every slot is the reference's EmptyObstacle (position -100, radius -100;
+      // mpcPlanner.py:18-26,127-133), as the host packer writes
+      for (int j = 0; j < 4 * O.nobst; j++) put(O.obst + j, -100.0);
     }
   }
   if (O.lin >= 0 && S.lin)
@@ -1739,6 +1743,8 @@ struct rmpc_handle {
   int64_t lane_bytes[RMPC_NUM_KERNELS] = {0};   // per active lane (pack/unpack: per call)
   double prof_bytes[RMPC_NUM_KERNELS] = {0};     // accumulated algorithmic bytes of the profiled launches
   std::vector<int> h_hist;
+  // debugging switches, read once at rmpc_create (never set by the product code)
+  bool env_no_migrate = false, env_dump_hist = false;
 };
 
 // Row tables in device memory (DevTables): kinematic slots with their FK rows, and the
@@ -1817,6 +1823,7 @@ static int build_model(const rmpc_desc &d, DevModel &M, std::string &err) {
   M.robot = d.robot; M.N = d.N; M.n = d.n; M.nx = d.nx; M.nu = d.nu; M.ns = d.ns;
   M.nv = d.nx + d.ns + d.nu; M.nw = d.ns + d.nu; M.npar = d.npar; M.dt = d.dt;
   if (d.N < 1 || d.N > 1000) { err = "horizon out of range"; return -1; }
+  if (d.n_joints < 1 || d.n_joints > RMPC_MAX_JOINTS) { err = "n_joints out of range"; return -1; }
   if (d.ns != 0 && d.ns != 1) { err = "ns must be 0 or 1"; return -1; }
   if (d.robot == RMPC_ROBOT_CHAIN) {
     if (d.nx != 2 * d.n || d.nu != d.n) { err = "holonomic chain needs nx = 2n, nu = n"; return -1; }
@@ -2063,10 +2070,10 @@ struct Phase {
 };
 
 template <class C>
-static void launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hipStream_t st, int which) {
+static int launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hipStream_t st, int which) {
   const int B = ph.B;
   const int lanes = ph.W.Bp * h->M.N;
-  if (ph.W.rs != C::RS) { fprintf(stderr, "rmpc: stage-record layout mismatch (%d != %d)\n", ph.W.rs, C::RS); abort(); }
+  if (ph.W.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
   if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B, first);
   else if (which == K_RICCATI) {
     if (C::IPB > 1 && B >= kGroupedMin)
@@ -2078,17 +2085,19 @@ static void launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hi
     hipLaunchKernelGGL((k_riccati<C, 1>), dim3(tail_blocks), dim3(64), 0, st, h->M, ph.W, B, first, pass);
   }
   else hipLaunchKernelGGL((k_step<C>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B);
+  return 0;
 }
 
-static void launch_variant(rmpc_handle *h, const Phase &ph, int first, int pass, hipStream_t st, int which) {
+static int launch_variant(rmpc_handle *h, const Phase &ph, int first, int pass, hipStream_t st, int which) {
   switch (h->variant) {
-    case 0: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>(h, ph, first, pass, st, which); break;
-    case 1: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 3, 1>>(h, ph, first, pass, st, which); break;
-    case 2: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 7, 0>>(h, ph, first, pass, st, which); break;
-    case 3: launch_pass<Cfg<RMPC_ROBOT_CHAIN, 7, 1>>(h, ph, first, pass, st, which); break;
-    case 4: launch_pass<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>(h, ph, first, pass, st, which); break;
-    case 5: launch_pass<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>(h, ph, first, pass, st, which); break;
+    case 0: return launch_pass<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>(h, ph, first, pass, st, which);
+    case 1: return launch_pass<Cfg<RMPC_ROBOT_CHAIN, 3, 1>>(h, ph, first, pass, st, which);
+    case 2: return launch_pass<Cfg<RMPC_ROBOT_CHAIN, 7, 0>>(h, ph, first, pass, st, which);
+    case 3: return launch_pass<Cfg<RMPC_ROBOT_CHAIN, 7, 1>>(h, ph, first, pass, st, which);
+    case 4: return launch_pass<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>(h, ph, first, pass, st, which);
+    case 5: return launch_pass<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>(h, ph, first, pass, st, which);
   }
+  return fail("no kernel variant");
 }
 
 static hipEvent_t prof_event(rmpc_handle *h) {
@@ -2147,13 +2156,14 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
   int pass = 0, next_check = 8;
   Phase ph{h->W, B};
   bool migrated = false;
-  const bool may_migrate = h->Bpc > 0 && B >= kMigrateMin && !getenv("RMPC_NO_MIGRATE");
+  const bool may_migrate = h->Bpc > 0 && B >= kMigrateMin && !h->env_no_migrate;
   for (; pass < cap; pass++) {
     const int first = pass == 0;
-    { ProfScope ps(h, st, K_SWEEP); launch_variant(h, ph, first, pass, st, K_SWEEP); }
-    { ProfScope ps(h, st, K_RICCATI); launch_variant(h, ph, first, pass, st, K_RICCATI); }
+    { ProfScope ps(h, st, K_SWEEP); if (launch_variant(h, ph, first, pass, st, K_SWEEP)) return -1; }
+    { ProfScope ps(h, st, K_RICCATI); if (launch_variant(h, ph, first, pass, st, K_RICCATI)) return -1; }
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, ph.W, ph.B, pass);
-    { ProfScope ps(h, st, K_STEP); launch_variant(h, ph, first, pass, st, K_STEP); }
+    { ProfScope ps(h, st, K_STEP); if (launch_variant(h, ph, first, pass, st, K_STEP)) return -1; }
+    if (h->profiling) HIPCHK(hipGetLastError());   // per pass when profiling is on (otherwise once after the loop)
     if (pass + 1 == next_check && max_passes_override <= 0) {
       HIPCHK(hipMemcpyAsync(h->h_active, h->W.active_hist + pass, sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
@@ -2189,7 +2199,7 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
     HIPCHK(hipMemcpyAsync(h->h_hist.data(), h->W.active_hist, sizeof(int) * pass, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     prof_collect(h);
-    if (getenv("RMPC_DUMP_HIST")) {  // development aid: instances still iterating after each pass
+    if (h->env_dump_hist) {  // development aid: instances still iterating after each pass
       fprintf(stderr, "rmpc active after pass:");
       for (int p = 0; p < pass; p++) fprintf(stderr, " %d", h->h_hist[p]);
       fprintf(stderr, "\n");
@@ -2211,6 +2221,10 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
 extern "C" {
 
 int rmpc_version(void) { return RMPC_VERSION; }
+#ifndef RMPC_SOURCE_HASH
+#define RMPC_SOURCE_HASH "unhashed"
+#endif
+const char *rmpc_source_hash(void) { return RMPC_SOURCE_HASH; }
 const char *rmpc_last_error(void) { return g_err.c_str(); }
 int rmpc_desc_size(void) { return (int)sizeof(rmpc_desc); }
 const char *rmpc_kernel_name(int idx) { return (idx >= 0 && idx < RMPC_NUM_KERNELS) ? kKernelNames[idx] : ""; }
@@ -2254,7 +2268,8 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   h->ws_bytes = big + (h->Bpc ? carve(h->M, h->Bpc, 0, nullptr, tmp) : 0);
   e = hipMalloc(&h->ws_base, h->ws_bytes);
   if (e != hipSuccess) { delete h; return fail(std::string("hipMalloc workspace: ") + hipGetErrorString(e)); }
-  (void)hipMemset(h->ws_base, 0, h->ws_bytes);
+  e = hipMemset(h->ws_base, 0, h->ws_bytes);
+  if (e != hipSuccess) { (void)hipFree(h->ws_base); delete h; return fail(std::string("hipMemset workspace: ") + hipGetErrorString(e)); }
   carve(h->M, h->Bp, h->max_passes, h->ws_base, h->W);
   if (h->Bpc) {
     carve(h->M, h->Bpc, 0, (char *)h->ws_base + big, h->Wc);
@@ -2263,8 +2278,11 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   e = hipMalloc((void **)&h->d_T, sizeof(DevTables));
   if (e == hipSuccess) e = hipMemcpy(h->d_T, &h->T, sizeof(DevTables), hipMemcpyHostToDevice);
   if (e != hipSuccess) { (void)hipFree(h->ws_base); delete h; return fail(std::string("row tables: ") + hipGetErrorString(e)); }
-  (void)hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-  (void)hipHostMalloc((void **)&h->h_active, sizeof(int), hipHostMallocDefault);
+  e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_active, sizeof(int), hipHostMallocDefault);
+  if (e != hipSuccess) { rmpc_destroy(h); return fail(std::string("stream / pinned word: ") + hipGetErrorString(e)); }
+  h->env_no_migrate = getenv("RMPC_NO_MIGRATE") != nullptr;
+  h->env_dump_hist = getenv("RMPC_DUMP_HIST") != nullptr;
   *out = h;
   return 0;
 }
@@ -2272,7 +2290,7 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
 void rmpc_destroy(rmpc_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipDeviceSynchronize();   // a solve enqueued on a caller's stream may still be reading the workspace
   void *bufs[] = {h->ws_base, (void *)h->d_T, h->d_xinit, h->d_x0, h->d_params, h->d_zout, h->d_kkt, h->d_obj, h->d_exit, h->d_iters};
   for (void *p : bufs) (void)hipFree(p);
   for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -2323,7 +2341,7 @@ int rmpc_solve_batch_device(rmpc_handle *h, int B, const double *d_xinit, const 
                             double *d_obj, void *stream) {
   if (!h || !d_xinit || !d_x0 || !d_params || !d_z_out || !d_exitflag || !d_iters || !d_kkt_res || !d_obj)
     return fail("null argument");
-  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  hipStream_t st = (hipStream_t)stream;   // NULL: the legacy null stream, ordered with the caller's default-stream work
   return solve_device(h, B, d_xinit, d_x0, d_params, d_z_out, d_exitflag, d_iters, d_kkt_res, d_obj, st, 0);
 }
 
@@ -2346,7 +2364,7 @@ int rmpc_pack_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene, doubl
   if (scene->struct_size != (int)sizeof(rmpc_scene)) return fail("rmpc_scene size mismatch");
   if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
   HIPCHK(hipSetDevice(h->device));
-  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  hipStream_t st = (hipStream_t)stream;   // NULL: the legacy null stream, ordered with the caller's default-stream work
   SceneDev S; SceneOff O;
   scene_args(h, scene, S, O);
   const int lanes = B * h->M.N;
@@ -2363,7 +2381,7 @@ int rmpc_solve_batch_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene
   if (scene->struct_size != (int)sizeof(rmpc_scene)) return fail("rmpc_scene size mismatch");
   if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
   HIPCHK(hipSetDevice(h->device));
-  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  hipStream_t st = (hipStream_t)stream;   // NULL: the legacy null stream, ordered with the caller's default-stream work
   SceneDev S; SceneOff O;
   scene_args(h, scene, S, O);
   const int lanes = h->Bp * h->M.N;
@@ -2376,7 +2394,7 @@ int rmpc_advance_device(rmpc_handle *h, int B, const double *d_z_prev, double *d
   if (!h || !d_z_prev || !d_xinit || !d_x0) return fail("null argument");
   if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
   HIPCHK(hipSetDevice(h->device));
-  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  hipStream_t st = (hipStream_t)stream;   // NULL: the legacy null stream, ordered with the caller's default-stream work
   const dim3 g((B + 255) / 256), t(256);
   switch (h->variant) {
     case 0: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
@@ -2441,7 +2459,7 @@ int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x
   dim3 g2((B + 63) / 64, (M.N * M.nv + 63) / 64);
   hipLaunchKernelGGL(k_pack, g2, dim3(256), 0, st, h->d_x0, h->W.z[0], B, M.N * M.nv, M.nv, M.N, h->Bp);
   hipLaunchKernelGGL(k_init, dim3((B + 255) / 256), dim3(256), 0, st, h->W, h->d_xinit, B, M.nx, M.mu0);
-  launch_variant(h, Phase{h->W, B}, 1, 0, st, K_SWEEP);
+  if (launch_variant(h, Phase{h->W, B}, 1, 0, st, K_SWEEP)) return -1;
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
   // gather SoA -> instance-major on the host (debug path, not timed)

@@ -11,13 +11,9 @@ from robot_mpcs_amd.models.mpcModel import MpcModel, ROBOT_DIFFDRIVE
 
 class MpcDiffDriveModel(MpcModel):
     def __init__(self, initParamMap=True, **kwargs):
-        super().__init__(initParamMap=initParamMap, **kwargs)
-        self._n = self._fk.n() + 3
-        self._nx = 2 * self._n + 2
-        self._nu = 2 + self._fk.n()
+        if kwargs['robot']['base_type'] != 'diffdrive':
+            raise ValueError("MpcDiffDriveModel needs robot.base_type: diffdrive")
+        super().__init__(initParamMap=initParamMap, **kwargs)   # dimensions: ModelContext (mpcBase.py:56-60)
 
     def robot_kind(self):
         return ROBOT_DIFFDRIVE
-
-    def get_velocity(self, z):
-        return z[2 * self._n: 2 * self._n + self._nu]

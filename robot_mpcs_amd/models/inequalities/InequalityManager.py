@@ -1,24 +1,19 @@
-"""Resolves the YAML ``constraints`` list to plug-in classes by name and
-builds the parameter map in YAML order (reference
-``robotmpcs/models/inequalities/InequalityManager.py:15-23``)."""
-from robot_mpcs_amd.models.mpcBase import MpcBase
+"""Instantiates the YAML ``constraints`` list, in YAML order, and lets every plug-in register its
+parameters (counterpart of reference ``InequalityManager.py:15-23``; the concatenation of the rows
+and their softening, ``:25-33``, happen in the kernels)."""
+from robot_mpcs_amd.models.mpcBase import ModelContext, ParamLayout
 
 
-class InequalityManager(MpcBase):
-
-    def __init__(self, ParamMap={}, npar=0, **kwargs):
-        super().__init__(**kwargs)
-        self._paramMap = ParamMap
-        self._npar = npar
-        self._kwargs = kwargs
-        self.inequality_modules = []
-        self.inequality_modules_strs = self._kwargs['mpc']['constraints']
-
-    def set_constraints(self):
+class InequalityManager:
+    def __init__(self, ctx: ModelContext, layout: ParamLayout):
         import robot_mpcs_amd.models.inequalities as registry
-        self.inequality_modules = []
-        for class_name in self.inequality_modules_strs:
-            class_ = getattr(registry, class_name)
-            self.inequality_modules.append(class_(**self._kwargs))
-            self._paramMap, self._npar = self.inequality_modules[-1].set_parameters(self._paramMap, self._npar)
-        return self._paramMap, self._npar
+        self.names = list(ctx.config.constraints)
+        self.modules = []
+        for name in self.names:
+            module = getattr(registry, name)(ctx)     # unknown name: AttributeError, as in the reference
+            module.register(layout)
+            self.modules.append(module)
+
+    @property
+    def number_inequalities(self) -> int:
+        return sum(m._n_ineq for m in self.modules)

@@ -1,121 +1,74 @@
-"""Inequality plug-in modules.
+"""Inequality plug-ins, table driven.
 
-Mirror of reference ``robotmpcs/models/inequalities/*.py``: one class per YAML
-name, each with ``_n_ineq`` and ``set_parameters(ParamMap, npar)`` that appends
-its entries to the parameter map in the reference order.  The symbolic
-``eval_constraint`` of the reference is replaced by the hand-written HIP
-device function selected by ``KIND`` (robot_mpcs_amd/csrc/rmpc_model.hpp); the
-row order inside each module is documented there and in DESIGN.md.
+The reference resolves the YAML ``constraints`` list to classes by name
+(``getattr(robotmpcs.models.inequalities, name)``, ``InequalityManager.py:17-21``)
+and asks each for its row count and its ``paramMap`` entries.  Here every plug-in
+is ONE row of ``SPECS``: the HIP kernel kind (``rmpc.h`` ``RMPC_MOD_*``; the
+arithmetic lives in ``csrc/rmpc_kernels.hip``), the number of rows and the
+parameter entries in registration order.  A class per YAML name is generated from
+the table so that the lookup by name -- and its ``AttributeError`` for unknown
+names -- stays what users of the reference expect.
+
+Row semantics (reference file:line):
+  RadialConstraints                 h = ||fk_l(q) - c_i|| - r_i - r_body, links outer, obstacles inner
+                                    (RadialConstraints.py:6-23, mpcBase.py:82-101; FIX undefined ``j`` at :22)
+  LinearConstraints                 h = |a.fk_l(q) + d| / ||a|| - r_body        (LinearConstraints.py:8-40)
+  SelfCollisionAvoidanceConstraints h = ||fk_a(q) - fk_b(q)|| - 2 r_body        (SelfCollision...py:8-27)
+  JointLimitConstraints             [q_j - lo_j, hi_j - q_j] interleaved        (JointLimitConstraints.py:8-31)
+  VelLimitConstraints               the same on the last two velocity states; FIX: 4 rows, the reference
+                                    declares ``_n_ineq = 2`` but returns 4      (VelLimitConstraints.py:8-31)
+  InputLimitConstraints             [u_j - lo_j, hi_j - u_j] interleaved        (InputLimitConstraints.py:7-29)
 """
-from robot_mpcs_amd.models.mpcBase import MpcBase
+from typing import Callable, List, NamedTuple, Tuple
 
-KIND_RADIAL = 0
-KIND_LINEAR = 1
-KIND_SELFCOLLISION = 2
-KIND_JOINTLIMIT = 3
-KIND_VELLIMIT = 4
-KIND_INPUTLIMIT = 5
+from robot_mpcs_amd.models.mpcBase import ModelContext, ParamLayout
 
 
-class RadialConstraints(MpcBase):
-    """h = ||fk_l(q) - c_i|| - r_i - r_body, links outer / obstacles inner
-    (reference ``RadialConstraints.py:6-23`` + ``mpcBase.py:82-101``; the
-    undefined ``j`` at ``RadialConstraints.py:22`` is a reference bug)."""
-    KIND = KIND_RADIAL
-
-    def __init__(self, **kwargs):
-        super().__init__(**kwargs)
-        self._n_ineq = self._config.number_obstacles * len(self._robot_config.collision_links)
-
-    def set_parameters(self, ParamMap, npar):
-        self._paramMap = ParamMap
-        self._npar = npar
-        self.addEntry2ParamMap("r_body", 1)
-        self.addEntry2ParamMap("obst", 4 * self._config.number_obstacles)
-        return self._paramMap, self._npar
+class Spec(NamedTuple):
+    kind: int                                                  # RMPC_MOD_* of include/rmpc.h
+    rows: Callable[[ModelContext], int]
+    params: Callable[[ModelContext], List[Tuple[str, int]]]     # (name, count) in registration order
 
 
-class LinearConstraints(MpcBase):
-    """h = |a.fk_l(q) + d| / ||a|| - r_body for planes [a, d]
-    (reference ``LinearConstraints.py:8-40``)."""
-    KIND = KIND_LINEAR
-
-    def __init__(self, **kwargs):
-        super().__init__(**kwargs)
-        self._n_ineq = self._config.number_obstacles * len(self._robot_config.collision_links)
-
-    def set_parameters(self, ParamMap, npar):
-        self._paramMap = ParamMap
-        self._npar = npar
-        self.addEntry2ParamMap("r_body", 1)
-        for i in range(self._config.number_obstacles):
-            self.addEntry2ParamMap("lin_constrs_" + str(i), 4)
-        return self._paramMap, self._npar
+def _fk_rows(c: ModelContext) -> int:
+    return c.config.number_obstacles * len(c.robot.collision_links)
 
 
-class SelfCollisionAvoidanceConstraints(MpcBase):
-    """h = ||fk_a(q) - fk_b(q)|| - 2 r_body per pair
-    (reference ``SelfCollisionAvoidanceConstraints.py:8-27``)."""
-    KIND = KIND_SELFCOLLISION
-
-    def __init__(self, **kwargs):
-        super().__init__(**kwargs)
-        self._n_ineq = len(self._robot_config.selfCollision['pairs'])
-
-    def set_parameters(self, ParamMap, npar):
-        self._paramMap = ParamMap
-        self._npar = npar
-        self.addEntry2ParamMap("r_body", 1)
-        return self._paramMap, self._npar
+SPECS = {
+    "RadialConstraints": Spec(0, _fk_rows, lambda c: [("r_body", 1), ("obst", 4 * c.config.number_obstacles)]),
+    "LinearConstraints": Spec(1, _fk_rows, lambda c: [("r_body", 1)] + [("lin_constrs_%d" % i, 4) for i in
+                                                                        range(c.config.number_obstacles)]),
+    "SelfCollisionAvoidanceConstraints": Spec(2, lambda c: len(c.robot.selfCollision['pairs']),
+                                              lambda c: [("r_body", 1)]),
+    "JointLimitConstraints": Spec(3, lambda c: 2 * c.n, lambda c: [("lower_limits", c.n), ("upper_limits", c.n)]),
+    "VelLimitConstraints": Spec(4, lambda c: 4, lambda c: [("lower_limits_vel", 2), ("upper_limits_vel", 2)]),
+    "InputLimitConstraints": Spec(5, lambda c: 2 * c.nu,
+                                  lambda c: [("lower_limits_u", c.nu), ("upper_limits_u", c.nu)]),
+}
 
 
-class JointLimitConstraints(MpcBase):
-    """interleaved [q_j - lo_j, hi_j - q_j] (reference
-    ``JointLimitConstraints.py:8-31``)."""
-    KIND = KIND_JOINTLIMIT
+class InequalityModule:
+    """One constraint plug-in bound to a model context."""
+    NAME = ""
 
-    def __init__(self, **kwargs):
-        super().__init__(**kwargs)
-        self._n_ineq = self._n * 2
+    def __init__(self, ctx: ModelContext):
+        self.spec = SPECS[self.NAME]
+        self.KIND = self.spec.kind
+        self._n_ineq = int(self.spec.rows(ctx))
+        self._params = self.spec.params(ctx)
 
-    def set_parameters(self, ParamMap, npar):
-        self._paramMap = ParamMap
-        self._npar = npar
-        self.addEntry2ParamMap("lower_limits", self._n)
-        self.addEntry2ParamMap("upper_limits", self._n)
-        return self._paramMap, self._npar
+    def register(self, layout: ParamLayout) -> None:
+        for name, count in self._params:
+            layout.add(name, count)
 
 
-class VelLimitConstraints(MpcBase):
-    """interleaved lower/upper limits on the last two velocity states
-    (reference ``VelLimitConstraints.py:8-31``; the reference declares
-    ``_n_ineq = 2`` but returns 4 rows -- 4 is used)."""
-    KIND = KIND_VELLIMIT
-
-    def __init__(self, **kwargs):
-        super().__init__(**kwargs)
-        self._n_ineq = 4
-
-    def set_parameters(self, ParamMap, npar):
-        self._paramMap = ParamMap
-        self._npar = npar
-        self.addEntry2ParamMap("lower_limits_vel", 2)
-        self.addEntry2ParamMap("upper_limits_vel", 2)
-        return self._paramMap, self._npar
+def _make(name):
+    return type(name, (InequalityModule,), {"NAME": name, "__doc__": "constraint plug-in '%s' (see SPECS)" % name})
 
 
-class InputLimitConstraints(MpcBase):
-    """interleaved [u_j - lo_j, hi_j - u_j] (reference
-    ``InputLimitConstraints.py:7-29``)."""
-    KIND = KIND_INPUTLIMIT
-
-    def __init__(self, **kwargs):
-        super().__init__(**kwargs)
-        self._n_ineq = self._nu * 2
-
-    def set_parameters(self, ParamMap, npar):
-        self._paramMap = ParamMap
-        self._npar = npar
-        self.addEntry2ParamMap("lower_limits_u", self._nu)
-        self.addEntry2ParamMap("upper_limits_u", self._nu)
-        return self._paramMap, self._npar
+RadialConstraints = _make("RadialConstraints")
+LinearConstraints = _make("LinearConstraints")
+SelfCollisionAvoidanceConstraints = _make("SelfCollisionAvoidanceConstraints")
+JointLimitConstraints = _make("JointLimitConstraints")
+VelLimitConstraints = _make("VelLimitConstraints")
+InputLimitConstraints = _make("InputLimitConstraints")

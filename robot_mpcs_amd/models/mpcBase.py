@@ -1,18 +1,20 @@
-"""Configuration dataclasses and dimension rules of the MPC model.
+"""Configuration schema and model dimensions of the MPC model.
 
-Mirror of reference ``robotmpcs/models/mpcBase.py``:
-``MpcConfiguration`` / ``RobotConfiguration`` (``:7-31``, identical field
-names, so unknown or missing YAML keys raise ``TypeError`` exactly as there),
-dimension rules n / nx / nu (``:52-60``), ``addEntry2ParamMap`` (``:68-71``)
-and the z layout ``[x(nx); s(ns); u(nu)]`` (``:76-80``).
+The two dataclasses are the config SCHEMA of the reference
+(``robotmpcs/models/mpcBase.py:7-31``): the YAML ``mpc`` / ``robot`` blocks are
+splatted into them, so unknown or missing keys raise ``TypeError`` exactly as
+there -- that is part of the drop-in contract and the field lists must match.
 
-Differences, both recorded in DESIGN.md: no CasADi / forwardkinematics objects
-are created (the chain constants are read from the URDF by
-``utils.urdf_chain``), and ``ns`` follows ``mpc.slack`` -- the reference hard
-codes ``_ns = 0`` (``:62``) which leaves ``slack: True`` broken (SURVEY.md 8a
-row A12); the intended design is implemented.
+Everything else is this project's own: ``ModelContext`` reads the URDF chain
+once (``utils.urdf_chain``; the reference re-creates a ``GenericURDFFk`` in every
+plug-in module) and derives the dimensions n / nx / nu / ns by the rules of
+``mpcBase.py:52-66``; ``ParamLayout`` is the append-only name -> index-list map
+behind ``paramMap.yaml`` (``addEntry2ParamMap``, ``:68-71``: an existing name is
+kept, not re-added).  ``ns`` follows ``mpc.slack`` -- the reference hard codes 0
+(``:62``), which leaves ``slack: True`` broken.
 """
 from dataclasses import dataclass
+from functools import lru_cache
 from typing import Dict, List
 
 from robot_mpcs_amd.utils.urdf_chain import UrdfChain, parse_chain
@@ -46,51 +48,47 @@ class RobotConfiguration:
     base_type: str
 
 
-class MpcBase(object):
-    _npar: int
-    _N: int
-    _pairs: List[int]
-    _paramMap: Dict[str, List[int]]
-    _modelName: str
+@lru_cache(maxsize=32)
+def _chain_of(urdf_file: str, root_link: str, end_link: str) -> UrdfChain:
+    with open(urdf_file, "r") as f:
+        return parse_chain(f.read(), root_link, end_link)
 
-    def __init__(self, **kwargs):
-        self._config = MpcConfiguration(**kwargs['mpc'])
-        self._debug = kwargs['example']['debug']
-        self._robot_config = RobotConfiguration(**kwargs['robot'])
-        with open(self._robot_config.urdf_file, 'r') as f:
-            urdf = f.read()
-        self._modelName = self._config.model_name
-        self._fk: UrdfChain = parse_chain(
-            urdf, self._robot_config.root_link, self._robot_config.end_link
-        )
-        self._m = 3
-        self._dt = self._config.time_step
-        if self._robot_config.base_type == 'holonomic':
-            self._n = self._fk.n()
-            self._nx = 2 * self._n
-            self._nu = self._n
-        elif self._robot_config.base_type == 'diffdrive':
-            self._n = self._fk.n() + 3
-            self._nx = 2 * self._n + 2
-            self._nu = 2 + self._fk.n()
+
+class ParamLayout:
+    """Ordered parameter map of one stage: name -> consecutive indices (``paramMap.yaml``)."""
+
+    def __init__(self):
+        self.entries: Dict[str, List[int]] = {}
+        self.size = 0
+
+    def add(self, name: str, count: int) -> None:
+        if name in self.entries:       # first registration wins (mpcBase.py:68-71)
+            return
+        self.entries[name] = list(range(self.size, self.size + int(count)))
+        self.size += int(count)
+
+    def offset(self, name: str) -> int:
+        return self.entries[name][0] if name in self.entries else -1
+
+
+class ModelContext:
+    """What every plug-in needs to know about the model: config, chain, dimensions."""
+    M_WORKSPACE = 3    # obstacle / goal dimension m (mpcBase.py:44)
+
+    def __init__(self, setup: dict):
+        self.config = MpcConfiguration(**setup['mpc'])
+        self.debug = setup['example']['debug']
+        self.robot = RobotConfiguration(**setup['robot'])
+        self.chain = _chain_of(self.robot.urdf_file, self.robot.root_link, self.robot.end_link)
+        dof = self.chain.n()
+        if self.robot.base_type == 'holonomic':          # mpcBase.py:52-55
+            self.n, self.nx, self.nu = dof, 2 * dof, dof
+        elif self.robot.base_type == 'diffdrive':        # mpcBase.py:56-60
+            self.n = dof + 3
+            self.nx, self.nu = 2 * self.n + 2, 2 + dof
         else:
-            raise ValueError(f"unknown base_type {self._robot_config.base_type}")
-        self._ns = 1 if self._config.slack else 0
-        self._n_obst = 0
-        self._m_obst = 3
-        self._pairs = []
-        self._N = self._config.time_horizon
-
-    def addEntry2ParamMap(self, name, n_par):
-        if name not in self._paramMap:
-            self._paramMap[name] = list(range(self._npar, self._npar + n_par))
-            self._npar += n_par
-
-    def get_velocity(self, z):
-        return z[self._n: self._nx]
-
-    def extractVariables(self, z):
-        q = z[0: self._n]
-        qdot = z[self._n: self._nx]
-        qddot = z[self._nx + self._ns: self._nx + self._ns + self._nu]
-        return q, qdot, qddot
+            raise ValueError(f"unknown base_type {self.robot.base_type}")
+        self.ns = 1 if self.config.slack else 0
+        self.m = self.M_WORKSPACE
+        self.N = int(self.config.time_horizon)
+        self.dt = self.config.time_step

@@ -25,7 +25,7 @@ from shutil import rmtree
 import numpy as np
 import yaml
 
-from robot_mpcs_amd.models.mpcBase import MpcBase
+from robot_mpcs_amd.models.mpcBase import ModelContext, ParamLayout
 from robot_mpcs_amd.models.inequalities.InequalityManager import InequalityManager
 from robot_mpcs_amd.models.objectives.ObjectiveManager import ObjectiveManager
 from robot_mpcs_amd.utils.urdf_chain import JOINT_FIXED
@@ -56,33 +56,36 @@ DEFAULT_OPTIONS = {
 }
 
 
-class MpcModel(MpcBase):
+class MpcModel:
     def __init__(self, initParamMap=True, **kwargs):
-        super().__init__(**kwargs)
+        self._ctx = ctx = ModelContext(kwargs)
         self._kwargs = kwargs
-
+        # names the reference's users (and makeSolver / the planner) read off the model object
+        self._config, self._robot_config, self._debug, self._fk = ctx.config, ctx.robot, ctx.debug, ctx.chain
+        self._n, self._nx, self._nu, self._ns, self._m, self._N = ctx.n, ctx.nx, ctx.nu, ctx.ns, ctx.m, ctx.N
+        self._dt = ctx.dt
+        self._modelName = ctx.config.model_name
+        self._layout = ParamLayout()
         if initParamMap:
+            # default box of the reference (mpcModel.py:23-27): x, u in [-100, 100], s in [0, inf)
             self._limits = {
-                "x": {"low": np.ones(self._nx) * -100, "high": np.ones(self._nx) * 100},
-                "u": {"low": np.ones(self._nu) * -100, "high": np.ones(self._nu) * 100},
-                "s": {"low": np.zeros(1), "high": np.ones(1) * np.inf},
+                "x": {"low": np.full(self._nx, -100.0), "high": np.full(self._nx, 100.0)},
+                "u": {"low": np.full(self._nu, -100.0), "high": np.full(self._nu, 100.0)},
+                "s": {"low": np.zeros(1), "high": np.full(1, np.inf)},
             }
-            self.initParamMap()
-        self._inequality_manager = InequalityManager(self._paramMap, self._npar, **kwargs)
-        self._paramMap, self._npar = self._inequality_manager.set_constraints()
-        self.number_inequalities = 0
-        for ineq_module in self._inequality_manager.inequality_modules:
-            self.number_inequalities += ineq_module._n_ineq
-
-        self._objective_manager = ObjectiveManager(
-            self._paramMap, self._npar, self._inequality_manager.inequality_modules, **kwargs
-        )
-        self._paramMap, self._npar = self._objective_manager.set_objectives()
+        self._inequality_manager = InequalityManager(ctx, self._layout)
+        self.number_inequalities = self._inequality_manager.number_inequalities
+        self._objective_manager = ObjectiveManager(ctx, self._layout)
         self._options = dict(DEFAULT_OPTIONS)
 
-    def initParamMap(self):
-        self._paramMap = {}
-        self._npar = 0
+    # paramMap.yaml content and its length, under the reference's attribute names
+    @property
+    def _paramMap(self):
+        return self._layout.entries
+
+    @property
+    def _npar(self):
+        return self._layout.size
 
     def setLimits(self, limits):
         self._limits = limits
@@ -111,7 +114,7 @@ class MpcModel(MpcBase):
             raise ValueError("kinematic chain longer than %d joints" % MAX_JOINTS)
         if self.robot_kind() == ROBOT_DIFFDRIVE and any(j.type != JOINT_FIXED for j in chain.joints):
             raise NotImplementedError("diff-drive base with an actuated arm (fk.n() > 0) is not supported")
-        modules = self._inequality_manager.inequality_modules
+        modules = self._inequality_manager.modules
         if len(modules) > MAX_MODULES:
             raise ValueError("more than %d constraint modules" % MAX_MODULES)
         links = [chain.frame_of(l) for l in self._robot_config.collision_links]
@@ -128,10 +131,9 @@ class MpcModel(MpcBase):
             lb = np.concatenate((self._limits["x"]["low"], self._limits["u"]["low"]))
             ub = np.concatenate((self._limits["x"]["high"], self._limits["u"]["high"]))
 
-        def off(name):
-            return int(self._paramMap[name][0]) if name in self._paramMap else -1
+        off = self._layout.offset
 
-        objectives = self._objective_manager.objective_modules_strs
+        objectives = self._objective_manager.names
         self._model = {
             "robot": self.robot_kind(),
             "N": int(self._N),
@@ -189,7 +191,7 @@ class MpcModel(MpcBase):
         with open(target + '/paramMap.yaml', 'w') as outfile:
             yaml.dump(self._paramMap, outfile, default_flow_style=False)
         properties = {"nx": self._nx, "nu": self._nu, "npar": self._npar, "ns": self._ns, "m": self._m,
-                      "constraints": self._inequality_manager.inequality_modules_strs}
+                      "constraints": self._inequality_manager.names}
         with open(target + '/properties.yaml', 'w') as outfile:
             yaml.dump(properties, outfile, default_flow_style=False)
         with open(target + '/' + DESCRIPTOR_FILE, 'w') as outfile:

@@ -1,37 +1,30 @@
-"""Objective plug-in modules (reference ``robotmpcs/models/objectives``).
+"""Objective plug-ins, table driven (reference ``robotmpcs/models/objectives``).
 
-``GoalReaching``: (fk_end(q) - goal)^T diag(wgoal) (fk_end(q) - goal)
-(reference ``goal_reaching.py:19-33``).
-``ConstraintAvoidance``: N * sum_i wconstr_i / h_i[0], first row of every
-non-empty inequality module (reference ``constraint_avoidance.py:22-31``; the
-redundant ``for j in range(N)`` there multiplies the term by N -- kept).
-The arithmetic lives in robot_mpcs_amd/csrc/rmpc_model.hpp.
+  GoalReaching         (fk_end(q) - goal)^T diag(wgoal) (fk_end(q) - goal)            goal_reaching.py:19-33
+  ConstraintAvoidance  N * sum_i wconstr_i / h_i[0] over the first row of every non-empty inequality
+                       module; the redundant ``for j in range(N)`` of the reference multiplies the term
+                       by N -- kept                                                    constraint_avoidance.py:22-31
+
+Each plug-in only contributes parameter entries here; the arithmetic is in csrc/rmpc_kernels.hip.
 """
-from robot_mpcs_amd.models.mpcBase import MpcBase
+from robot_mpcs_amd.models.mpcBase import ModelContext, ParamLayout
+
+SPECS = {
+    "GoalReaching": lambda c: [("goal", c.m), ("wgoal", c.m)],
+    "ConstraintAvoidance": lambda c: [("wconstr", len(c.config.constraints))],
+}
 
 
-class GoalReaching(MpcBase):
+class ObjectiveModule:
+    NAME = ""
 
-    def __init__(self, ineq_modules, **kwargs):
-        super().__init__(**kwargs)
+    def __init__(self, ctx: ModelContext):
+        self._params = SPECS[self.NAME](ctx)
 
-    def set_parameters(self, ParamMap, npar):
-        self._paramMap = ParamMap
-        self._npar = npar
-        self.addEntry2ParamMap("goal", self._m)
-        self.addEntry2ParamMap("wgoal", self._m)
-        return self._paramMap, self._npar
+    def register(self, layout: ParamLayout) -> None:
+        for name, count in self._params:
+            layout.add(name, count)
 
 
-class ConstraintAvoidance(MpcBase):
-
-    def __init__(self, ineq_modules, **kwargs):
-        super().__init__(**kwargs)
-        self._n_constr_types = len(kwargs['mpc']['constraints'])
-        self._ineq_modules = ineq_modules
-
-    def set_parameters(self, ParamMap, npar):
-        self._paramMap = ParamMap
-        self._npar = npar
-        self.addEntry2ParamMap('wconstr', self._n_constr_types)
-        return self._paramMap, self._npar
+GoalReaching = type("GoalReaching", (ObjectiveModule,), {"NAME": "GoalReaching"})
+ConstraintAvoidance = type("ConstraintAvoidance", (ObjectiveModule,), {"NAME": "ConstraintAvoidance"})

@@ -48,11 +48,70 @@ def test_two_rank_sharding_and_stats_gather(tmp_path, oracle_lib):
     z = np.concatenate([p["z"] for p in parts])
     assert np.array_equal(z, full["z"])
     # every rank holds the same gathered statistics; max-over-ranks time is the slowest rank's
-    assert np.array_equal(parts[0]["allstats"], parts[1]["allstats"]) and parts[0]["allstats"].shape == (2, 6)
+    assert np.array_equal(parts[0]["allstats"], parts[1]["allstats"]) and parts[0]["allstats"].shape == (2, fleet.N_STATS)
     s = fleet.summarize(parts[0]["allstats"], instances_per_rank=23 / 2)
     assert s["converged"] == int((full["exitflag"] == 1).sum()) and s["iters_max"] == int(full["iters"].max())
     assert abs(s["iters_mean"] - full["iters"].mean()) < 1e-12
     assert float(parts[0]["tmax"]) == 2.0 and float(parts[1]["tmax"]) == 2.0
+
+
+def _mixed_worker(rank, world, port, outdir):
+    """One rank of the mixed fleet (BASELINE configs[4]): per-robot-type blocks, one homogeneous solve per type,
+    one gather of the statistics per type -- the collectives bench.py --config cfg5 issues over RCCL."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle.oracle import Oracle
+    from robot_mpcs_amd import fleet
+    from robot_mpcs_amd.scenarios import make_scenario
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = 16
+    part = fleet.partition_mixed(total, world)[rank]
+    out = {}
+    for cfg, (lo, hi) in part.items():
+        n_type = fleet.partition_mixed(total, 1)[0][cfg][1]
+        sc = make_scenario(cfg, B=n_type, seed=5, time_horizon=6)
+        r = Oracle(sc.desc).solve_batch(sc.xinit[lo:hi], sc.x0[lo:hi], sc.params[lo:hi], nthreads=2)
+        kkt = np.maximum(r["res_stat"], r["res_comp"])
+        out[cfg + "_stats"] = fleet.gather_stats(fleet.solve_stats(r["exitflag"], r["iters"], kkt), dist)
+        out[cfg + "_z"] = r["z"]
+        out[cfg + "_span"] = np.array([lo, hi])
+    np.savez(os.path.join(outdir, f"mixed{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_mixed_fleet_partition(tmp_path, oracle_lib):
+    world, port = 2, 31000 + (os.getpid() % 2000)
+    mp.spawn(_mixed_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from oracle.oracle import Oracle
+    from robot_mpcs_amd import fleet
+    from robot_mpcs_amd.scenarios import make_scenario
+    parts = [np.load(os.path.join(str(tmp_path), f"mixed{r}.npz")) for r in range(world)]
+    counts = {cfg: hi for cfg, (lo, hi) in fleet.partition_mixed(16, 1)[0].items()}
+    assert counts == {"cfg2": 8, "cfg3": 6, "cfg4": 2}
+    for cfg, n_type in counts.items():
+        sc = make_scenario(cfg, B=n_type, seed=5, time_horizon=6)
+        full = Oracle(sc.desc).solve_batch(sc.xinit, sc.x0, sc.params, nthreads=2)
+        assert parts[0][cfg + "_span"][0] == 0 and parts[0][cfg + "_span"][1] == parts[1][cfg + "_span"][0]
+        assert parts[1][cfg + "_span"][1] == n_type
+        assert np.array_equal(np.concatenate([p[cfg + "_z"] for p in parts]), full["z"])
+        assert np.array_equal(parts[0][cfg + "_stats"], parts[1][cfg + "_stats"])
+        s = fleet.summarize(parts[0][cfg + "_stats"], instances_per_rank=n_type / 2)
+        assert s["converged"] + s["acceptable"] == int(np.isin(full["exitflag"], (1, 2)).sum())
+
+
+def test_partition_mixed_is_the_survey_partition():
+    from robot_mpcs_amd.fleet import partition_mixed
+    parts = partition_mixed(65536, 8)
+    assert len(parts) == 8
+    for r, p in enumerate(parts):
+        assert {k: hi - lo for k, (lo, hi) in p.items()} == {"cfg2": 4096, "cfg3": 3072, "cfg4": 1024}
+        assert p["cfg2"][0] == r * 4096 and p["cfg3"][0] == r * 3072 and p["cfg4"][0] == r * 1024
+    one = partition_mixed(8192, 1)[0]
+    assert {k: hi - lo for k, (lo, hi) in one.items()} == {"cfg2": 4096, "cfg3": 3072, "cfg4": 1024}
 
 
 def test_shard_range_properties():

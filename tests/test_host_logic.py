@@ -187,3 +187,99 @@ def test_closed_loop_golden_trace_reproduces_from_oracle(oracle_lib):
     np.testing.assert_allclose(xs, g["xs"], rtol=0, atol=1e-9)
     np.testing.assert_allclose(us, g["us"], rtol=0, atol=1e-9)
     assert xs[-1][0] > xs[0][0] + 2.0   # it does drive towards the goal
+
+
+# ---------------------------------------------------------------------------------------------------
+# tooling parity: makeSolver argv contract, ROS-style YAML, set_mpc_parameter dispatcher
+# ---------------------------------------------------------------------------------------------------
+def _load_make_solver():
+    import importlib.util
+    path = os.path.join(os.path.dirname(CONFIG_DIR), "makeSolver.py")
+    spec = importlib.util.spec_from_file_location("makeSolver_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_make_solver_accepts_the_reference_argv_form(tmp_path):
+    """reference examples/makeSolver.py:26-29: robot type = text between the last '/' and 'Mpc' (regex
+    '\\/(\\S*)M'), file read = config/<type>Mpc.yaml"""
+    ms = _load_make_solver()
+    assert ms.setup_file_from_argv("config/pointRobotMpc.yaml") == "config/pointRobotMpc.yaml"
+    assert ms.setup_file_from_argv("config/boxerMpc.yaml") == "config/boxerMpc.yaml"
+    assert ms.setup_file_from_argv("x/pandaMpc.yaml") == "config/pandaMpc.yaml"   # as in the reference only the type counts
+    absolute = os.path.join(CONFIG_DIR, "cfg2_pointRobotMpc.yaml")
+    assert ms.setup_file_from_argv(absolute) == absolute
+
+
+def test_ros_style_yaml_without_objectives_key(tmp_path):
+    """ros_bridge/.../config/boxer_mpc_config.yaml:2-22 (from the fixture of the reference's files): no
+    ``objectives`` key, no ``example`` block, obstacle weight under ``wobst``."""
+    import json
+    from robot_mpcs_amd.utils.utils import normalise_setup
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_pins.json")))
+    ros = pins["configs"]["boxer_ros"]
+    assert "objectives" not in ros["mpc"] and "example" not in ros
+    with pytest.raises(TypeError):
+        MpcConfiguration(**ros["mpc"])           # the strict schema still rejects it, like the reference
+    norm = normalise_setup(ros)
+    assert norm["mpc"]["objectives"] == ["GoalReaching", "ConstraintAvoidance"]
+    assert norm["mpc"]["weights"]["wconstr"] == [0.5, 0.0, 0.0, 0.0] and norm["mpc"]["weights"]["ws"] == 1e10
+    assert "objectives" not in ros["mpc"]        # input untouched
+    yfile = tmp_path / "boxer_mpc_config.yaml"
+    yfile.write_text(yaml.dump(ros))
+    model, setup = build_model(str(yfile))
+    target = model.generateSolver(location=str(tmp_path) + "/")
+    assert os.path.basename(target) == "boxer_n3_01_H10_noSlack"
+    assert model._paramMap["wconstr"] == [model._npar - 4 + i for i in range(4)] and model.number_inequalities == 1 + 0 + 6 + 4
+    MpcConfiguration(**setup["mpc"])
+    complete = normalise_setup(setup)
+    assert complete["mpc"] == setup["mpc"]       # complete configs pass through unchanged
+
+
+class _RecordingPlanner:
+    def __init__(self):
+        self.calls = []
+
+    def concretize(self): self.calls.append(("concretize",))
+    def reset(self): self.calls.append(("reset",))
+
+    def __getattr__(self, name):
+        if name.startswith("set"):
+            return lambda *a: self.calls.append((name,) + a)
+        raise AttributeError(name)
+
+
+def test_set_mpc_parameter_dispatch_follows_the_reference(capsys):
+    """reference examples/mpc_example.py:63-119: objectives first, then constraints, each in YAML order; the
+    limits are handed over transposed; a missing scene attribute prints the reference's message and exits 1."""
+    from robot_mpcs_amd.planner.harness import MpcHarness, SphereObstacle, StaticGoal
+    rec = _RecordingPlanner()
+    h = MpcHarness("config/wc_boxerMpc.yaml", planner=rec)
+    assert h._robot_type == "wc_boxer" and rec.calls == [("concretize",), ("reset",)]
+    h._goal = StaticGoal([7.2, -2.2])
+    h._limits = np.array([[-10, 10], [-10, 10], [-10, 10.0]])
+    h._limits_u = np.array([[-10, 10], [-10, 10.0]])
+    h._limits_vel = np.array([[-1.2, 1.2], [-1.5, 1.5]])
+    h._lin_constr = np.zeros((10, 2, 4)); h._r_body = 0.6
+    h.set_mpc_parameter()
+    names = [c[0] for c in rec.calls[2:]]
+    assert names == ["setGoalReaching", "setConstraintAvoidance", "setLinearConstraints",
+                     "setSelfCollisionAvoidanceConstraints", "setJointLimits", "setVelLimits", "setInputLimits"]
+    assert rec.calls[2][1] == [7.2, -2.2]
+    np.testing.assert_array_equal(rec.calls[6][1], h._limits.T)        # (2, n): limits[0] lower, limits[1] upper
+    np.testing.assert_array_equal(rec.calls[7][1], h._limits_vel.T)
+    # missing attribute
+    h2 = MpcHarness("config/pointRobotMpc.yaml", planner=_RecordingPlanner())
+    h2._goal = StaticGoal([8.2, -0.2]); h2._obstacles = [SphereObstacle([4.0, -0.5, 0.0], 1.0)]
+    h2._limits = np.zeros((3, 2)); h2._limits_u = np.zeros((3, 2))   # _r_body is not set
+    with pytest.raises(SystemExit) as ex:
+        h2.set_mpc_parameter()
+    assert ex.value.code == 1
+    assert "The required attributes for setting RadialConstraints are not defined" in capsys.readouterr().out
+    # unknown names
+    h3 = MpcHarness("config/pointRobotMpc.yaml", planner=_RecordingPlanner())
+    h3._config["mpc"]["objectives"] = ["NoSuchObjective"]
+    with pytest.raises(SystemExit):
+        h3.set_mpc_parameter()
+    assert "No function to set the parameters for this objective is defined" in capsys.readouterr().out

@@ -8,7 +8,10 @@ from oracle import nlp_numpy as ref
 from oracle.oracle import Oracle
 from robot_mpcs_amd.scenarios import make_scenario
 
-CASES = ["cfg1", "cfg2", "cfg3", "cfg4", "boxer"]
+CASES = ["cfg1", "cfg2", "cfg3", "cfg4", "boxer",
+         # VelLimitConstraints rows; ConstraintAvoidance weight non-zero on every module (Linear, SelfCollision,
+         # Joint / Vel / Input limits as "first row of a module")
+         "wc_point", "wc_boxer", "wc_boxer_slack", "wc_panda"]
 
 
 def _random_points(sc, o, rng, k=6):
@@ -130,3 +133,26 @@ def test_param_map_layout_matches_survey():
     assert sc.model._npar == 38 and sc.model.number_inequalities == 15
     sc = make_scenario("cfg3", B=1)
     assert sc.model._npar == 44 and sc.model._ns == 1 and sc.model.number_inequalities == 15
+
+
+def test_vel_limit_rows_follow_the_reference_module(oracle_lib):
+    """VelLimitConstraints.py:8-31 with the 4-row fix: rows [v - lo_v, hi_v - v, w - lo_w, hi_w - w] on the last
+    two velocity states (boxer: x[6], x[7]), placed in YAML order between the joint and the input limits."""
+    sc = make_scenario("wc_boxer", B=1, seed=0)
+    d, o = sc.desc, Oracle(sc.desc)
+    assert d["module_kind"] == [1, 2, 3, 4, 5] and d["nh"] == 2 + 0 + 6 + 4 + 4
+    pm = sc.model._paramMap
+    assert pm["lower_limits_vel"] == [d["off_lower_vel"], d["off_lower_vel"] + 1]
+    z = np.array([0.3, -0.2, 0.4, 0, 0, 0, 0.7, -0.9, 1.0, -2.0])
+    p = sc.params[0].reshape(o.N, o.npar)[3]
+    e = o.eval_stage(z, p)
+    lo, hi = p[pm["lower_limits_vel"]], p[pm["upper_limits_vel"]]
+    r0 = 2 + 6
+    np.testing.assert_allclose(e["g"][r0: r0 + 4], [z[6] - lo[0], hi[0] - z[6], z[7] - lo[1], hi[1] - z[7]], atol=0)
+    J = np.zeros((4, 10)); J[0, 6] = 1; J[1, 6] = -1; J[2, 7] = 1; J[3, 7] = -1
+    np.testing.assert_array_equal(e["Jg"][r0: r0 + 4], J)
+    # ConstraintAvoidance on the module: N * w / (first row), pre-slack (constraint_avoidance.py:22-31)
+    w = p[pm["wconstr"]]
+    expect = d["N"] * (w[0] / e["g"][0] + w[2] / e["g"][2] + w[3] / e["g"][r0] + w[4] / e["g"][r0 + 4])
+    base = dict(d); base["has_avoid"] = 0
+    np.testing.assert_allclose(e["f"] - Oracle(base).eval_stage(z, p)["f"], expect, rtol=1e-13)
