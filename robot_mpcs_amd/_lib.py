@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librmpc_hip.so")
+LIB_PATH = os.environ.get("RMPC_LIB_PATH") or os.path.join(_HERE, "csrc", "librmpc_hip.so")
 
 MAX_JOINTS, MAX_LINKS, MAX_PAIRS, MAX_MODULES, NV_MAX = 8, 8, 4, 8, 24
 NUM_KERNELS = 5
@@ -151,6 +151,8 @@ def load_library(path: str = LIB_PATH):
     if L.rmpc_desc_size() != C.sizeof(RmpcDesc):
         raise RmpcError("rmpc_desc layout mismatch between _lib.py and librmpc_hip.so")
     want = _source_hash()
+    if os.environ.get("RMPC_ALLOW_STALE"):   # development aid (A/B against an older build); never set by product code
+        want = None
     if want is not None and L.rmpc_source_hash().decode() != want:
         raise RmpcError("librmpc_hip.so is stale: built from other sources than the ones next to it "
                         f"({L.rmpc_source_hash().decode()} != {want}); run __graft_entry__.build()")

@@ -299,49 +299,45 @@ __device__ __forceinline__ void for_range(F &&fn) {
 //   * single-variable rows (limits and simple bounds), grouped by variable (static
 //     loops; absent entries load row 0 and are masked -- a branch around a load,
 //     even a wave-uniform one, makes hipcc wait for every element separately).
-template <class C>
-__global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
-                                               const int B, const int first) {
-  constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV;
-  const DevTables &T = *Tp;
-  const int gid = blockIdx.x * kSweepBlock + threadIdx.x;
-  const int li = gid % W.Bp;   // position in the compacted list of iterating instances
-  const int k = gid / W.Bp;    // uniform per wavefront (Bp % 64 == 0)
-  if (li >= *W.n_act || k >= M.N) return;
-  const int b = W.act_idx[li];
-  if (W.status[b] != ST_ACTIVE) return;
-  const int N = M.N;
-  // element offset of this lane inside a slot (32-bit, so that accesses become uniform base + lane offset) and slot size
-  const unsigned loff = (unsigned)k * (unsigned)W.Bp + (unsigned)b;
-  const size_t SS = (size_t)N * W.Bp;
-  const int cur = W.cur[b], nxt = cur ^ 1;
-  const double *__restrict__ zc = W.z[cur];
-  const double *__restrict__ tc = W.t[cur];
-  const double *__restrict__ lc = W.lam[cur];
-  const double *__restrict__ nc = W.nu[cur];
-  double *__restrict__ zn = W.z[nxt];
-  double *__restrict__ tn = W.t[nxt];
-  double *__restrict__ ln = W.lam[nxt];
-  double *__restrict__ nn = W.nu[nxt];
-  const double *__restrict__ pp = W.p;
-  const double *__restrict__ dzp = W.dz;
-  const double *__restrict__ gro = W.grow[cur];   // row values and FK-row gradients at the current iterate:
-  const double *__restrict__ jqo = W.Jq[cur];     //  the slack / multiplier steps are recomputed from them
-  double *__restrict__ grn = W.grow[nxt];
-  double *__restrict__ jqn = W.Jq[nxt];
-  const double *__restrict__ nup = W.nunew;
-  const double mu = W.mu[b];
-  double *__restrict__ rec = (double *)__builtin_assume_aligned(W.R, 128) + ((size_t)b * N + k) * C::RS;   // this lane's stage record (64-byte aligned: neighbouring entries leave as 16-byte stores)
+// What one lane -- one (instance, stage) pair -- of the stage-parallel sweep addresses.  Element `slot` of an
+// array is ptr[slot * SS + loff]: the batch-minor SoA of the pass kernels (SS = N * Bp, loff = k * Bp + b,
+// next stage kstride = Bp) and the per-instance layout of the fused kernel ([instance][slot][32 stages]:
+// SS = 32, loff = k, kstride = 1, pointers advanced to the instance) run the same code.
+struct SweepIO {
+  const double *zc, *tc, *lc, *nc, *pp, *dzp, *gro, *jqo, *nup;   // iterate (current buffer), parameters, step
+  double *zn, *tn, *ln, *nn, *grn, *jqn, *gfa;                    // trial point (other buffer), cost gradient
+  double *rec;                                                     // this lane's stage record
+  size_t SS;
+  unsigned loff, kstride;
+};
+// merit / KKT partial sums of one stage (order = enum Part)
+struct Partials { double f, th, logs, rstat, req, rineq, rcomp, sumc, minc, bad; };
 
-  // ---- step lengths of this trial --------------------------------------
-  // null pass: the current point is re-evaluated unchanged so that the step can be
-  // recomputed with the Gauss-Newton blocks (fallback of a failed curvature step)
-  const bool nostep = first || (W.redo[b] != 0);
-  double alpha = 0.0, adual = 0.0;
-  if (!nostep) {
-    alpha = ldexp(__longlong_as_double((long long)W.amin_p[b]), -W.ls[b]);
-    adual = __longlong_as_double((long long)W.amin_d[b]);
-  }
+template <class C>
+__device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T, const SweepIO &io, const int k,
+                                           const bool first, const bool nostep, const double alpha, const double adual,
+                                           const double mu, Partials &out) {
+  constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV;
+  const int N = M.N;
+  const unsigned loff = io.loff;
+  const size_t SS = io.SS;
+  const double *__restrict__ zc = io.zc;
+  const double *__restrict__ tc = io.tc;
+  const double *__restrict__ lc = io.lc;
+  const double *__restrict__ nc = io.nc;
+  double *__restrict__ zn = io.zn;
+  double *__restrict__ tn = io.tn;
+  double *__restrict__ ln = io.ln;
+  double *__restrict__ nn = io.nn;
+  const double *__restrict__ pp = io.pp;
+  const double *__restrict__ dzp = io.dzp;
+  const double *__restrict__ gro = io.gro;   // row values and FK-row gradients at the current iterate:
+  const double *__restrict__ jqo = io.jqo;   //  the slack / multiplier steps are recomputed from them
+  double *__restrict__ grn = io.grn;
+  double *__restrict__ jqn = io.jqn;
+  const double *__restrict__ nup = io.nup;
+  double *__restrict__ gfa = io.gfa;
+  double *__restrict__ rec = (double *)__builtin_assume_aligned(io.rec, 64);   // 64-byte aligned: neighbouring entries leave as 16-byte stores
   const double am = nostep ? 0.0 : alpha;   // multiplies the steps (0 on first / null passes:
   const double dm = nostep ? 0.0 : adual;   //  the steps are stale but finite)
 
@@ -351,8 +347,7 @@ __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevMo
   {
 #pragma unroll
     for (int j = 0; j < NV; j++) { zo[j] = zc[IDXL(j)]; dzo[j] = dzp[IDXL(j)]; }
-    const int k1 = k < N - 1 ? k + 1 : k;  // clamped: loads stay unconditional
-    const unsigned loff1 = (unsigned)k1 * (unsigned)W.Bp + (unsigned)b;
+    const unsigned loff1 = loff + (k < N - 1 ? io.kstride : 0u);  // next stage, clamped: loads stay unconditional
     double x1[NX], dx1[NX], n0[NX], n0n[NX], n1[NX], n1n[NX];
 #pragma unroll
     for (int j = 0; j < NX; j++) {
@@ -537,7 +532,7 @@ __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevMo
     if constexpr (NS > 0) rec[C::R_CS + j] = cs[j];
     rec[C::R_Q0 + j] = gf[j] + q0[j];
     rec[C::R_Q1 + j] = q1[j];
-    W.gfa[IDXL(j)] = gf[j];
+    gfa[IDXL(j)] = gf[j];
   };
   constexpr bool CHAIN = (C::ROBOT == RMPC_ROBOT_CHAIN);
   // The arm: velocity and input variables first, so that their accumulators are dead before the kinematics
@@ -770,7 +765,7 @@ __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevMo
     for (int j = 0; j < NV; j++) {
       rec[C::R_Q0 + j] = gf[j] + q0[j];
       rec[C::R_Q1 + j] = q1[j];
-      W.gfa[IDXL(j)] = gf[j];
+      gfa[IDXL(j)] = gf[j];
     }
   }
 
@@ -793,16 +788,55 @@ __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevMo
   rec[C::R_ZERO] = 0.0;
   const double logsum = log(lprod) + 0.6931471805599453094 * (double)lexp;
   if (!isfinite(f) || !isfinite(theta) || !isfinite(logsum)) bad = 1;
-  W.part[IDXL(P_F)] = f;
-  W.part[IDXL(P_TH)] = theta;
-  W.part[IDXL(P_LOGS)] = logsum;
-  W.part[IDXL(P_RSTAT)] = rstat;
-  W.part[IDXL(P_REQ)] = req;
-  W.part[IDXL(P_RINEQ)] = rineq;
-  W.part[IDXL(P_RCOMP)] = rcomp;
-  W.part[IDXL(P_SUMC)] = sumc;
-  W.part[IDXL(P_MINC)] = minc;
-  W.part[IDXL(P_BAD)] = (double)bad;
+  out.f = f; out.th = theta; out.logs = logsum; out.rstat = rstat; out.req = req; out.rineq = rineq;
+  out.rcomp = rcomp; out.sumc = sumc; out.minc = minc; out.bad = (double)bad;
+}
+
+template <class C>
+__global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
+                                               const int B, const int first) {
+  const int gid = blockIdx.x * kSweepBlock + threadIdx.x;
+  const int li = gid % W.Bp;   // position in the compacted list of iterating instances
+  const int k = gid / W.Bp;    // uniform per wavefront (Bp % 64 == 0)
+  if (li >= *W.n_act || k >= M.N) return;
+  const int b = W.act_idx[li];
+  if (W.status[b] != ST_ACTIVE) return;
+  const int N = M.N;
+  (void)B;
+  const int cur = W.cur[b], nxt = cur ^ 1;
+  SweepIO io;
+  io.zc = W.z[cur]; io.tc = W.t[cur]; io.lc = W.lam[cur]; io.nc = W.nu[cur];
+  io.zn = W.z[nxt]; io.tn = W.t[nxt]; io.ln = W.lam[nxt]; io.nn = W.nu[nxt];
+  io.pp = W.p; io.dzp = W.dz; io.gro = W.grow[cur]; io.jqo = W.Jq[cur]; io.grn = W.grow[nxt]; io.jqn = W.Jq[nxt];
+  io.nup = W.nunew; io.gfa = W.gfa;
+  io.rec = W.R + ((size_t)b * N + k) * C::RS;   // this lane's stage record
+  // element offset of this lane inside a slot (32-bit, so that accesses become uniform base + lane offset) and slot size
+  io.loff = (unsigned)k * (unsigned)W.Bp + (unsigned)b;
+  io.kstride = (unsigned)W.Bp;
+  io.SS = (size_t)N * W.Bp;
+  // ---- step lengths of this trial --------------------------------------
+  // null pass: the current point is re-evaluated unchanged so that the step can be
+  // recomputed with the Gauss-Newton blocks (fallback of a failed curvature step)
+  const bool nostep = first || (W.redo[b] != 0);
+  double alpha = 0.0, adual = 0.0;
+  if (!nostep) {
+    alpha = ldexp(__longlong_as_double((long long)W.amin_p[b]), -W.ls[b]);
+    adual = __longlong_as_double((long long)W.amin_d[b]);
+  }
+  Partials pt;
+  sweep_body<C>(M, *Tp, io, k, first != 0, nostep, alpha, adual, W.mu[b], pt);
+  const unsigned loff = io.loff;
+  const size_t SS = io.SS;
+  W.part[IDXL(P_F)] = pt.f;
+  W.part[IDXL(P_TH)] = pt.th;
+  W.part[IDXL(P_LOGS)] = pt.logs;
+  W.part[IDXL(P_RSTAT)] = pt.rstat;
+  W.part[IDXL(P_REQ)] = pt.req;
+  W.part[IDXL(P_RINEQ)] = pt.rineq;
+  W.part[IDXL(P_RCOMP)] = pt.rcomp;
+  W.part[IDXL(P_SUMC)] = pt.sumc;
+  W.part[IDXL(P_MINC)] = pt.minc;
+  W.part[IDXL(P_BAD)] = pt.bad;
 }
 
 // ===========================================================================
@@ -867,135 +901,122 @@ __device__ __forceinline__ double wave_min(double v) {
   return v;
 }
 
-template <class C, int IPB>
-__global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel M, const Ws W, const int B, const int first,
-                                                const int pass) {
-  constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV, NW = C::NW;
-  constexpr bool DD = (C::ROBOT == RMPC_ROBOT_DIFFDRIVE);
-  // IPB wavefronts per block work on IPB consecutive list entries: neighbouring instances share
-  // the 128-byte lines of the batch-minor arrays, so most of a wave's requests hit the CU's L1
-  // Two instantiations are launched every pass and pick their regime from the list length:
-  // the grouped one (IPB = C::IPB) while many instances iterate, the one-wave blocks (IPB = 1,
-  // static LDS addresses, lowest latency) in the iteration tail.
-  const int nact = *W.n_act;
-  if constexpr (C::IPB > 1) {
-    if ((IPB > 1) != (nact >= kGroupedMin)) return;
-  }
-  // lanes per instance: a whole wavefront, or half of one in the grouped regime of the small models (their
-  // dense blocks have few rows: two instances per wavefront halve the LDS instructions an instance costs, and
-  // LDS instruction throughput is what bounds this kernel when the whole batch iterates)
-  constexpr int LPI = (IPB > 1) ? C::RIC_LPI : 64;
-  constexpr int IPW = 64 / LPI;
-  const int wv = threadIdx.x / LPI;   // instance slot within the block
-  const int li = blockIdx.x * (IPB * IPW) + wv;
-  if (li >= nact) return;
-  const int b = W.act_idx[li];
-  if (W.status[b] != ST_ACTIVE) return;  // uniform over the lanes of an instance (whole wavefront, or one half in the grouped regime)
-  const int lane = threadIdx.x & (LPI - 1);
+// ---- per-instance solver state ------------------------------------------------------------------------
+// One set of words per instance.  The pass kernels keep them in the workspace (arrays over the batch), the
+// fused kernel in registers of the wavefront that owns the instance; the decision logic is the same code.
+struct Inst {
+  double mu, rho, phi0, Dd, fcur, thcur, logcur, res_stat, res_eq, res_ineq, res_comp, obj;
+  double amin_p, amin_d;   // fraction-to-the-boundary step lengths of the current step
+  int status, iters, ls, ls0, lsst, cur, newstep, redo, force_gn, gn_sticky, curv_fail, usedc, stall;
+};
+__device__ __forceinline__ void inst_init(Inst &s, double mu0) {
+  s.mu = mu0; s.rho = 0.0; s.phi0 = 0.0; s.Dd = 0.0; s.fcur = 0.0; s.thcur = 0.0; s.logcur = 0.0;
+  s.res_stat = 0.0; s.res_eq = 0.0; s.res_ineq = 0.0; s.res_comp = 0.0; s.obj = 0.0;
+  s.amin_p = 1.0; s.amin_d = 1.0;
+  s.status = ST_ACTIVE; s.iters = 0; s.ls = 0; s.ls0 = 0; s.lsst = 0; s.cur = 0; s.newstep = 0; s.redo = 0;
+  s.force_gn = 0; s.gn_sticky = 0; s.curv_fail = 0; s.usedc = 0; s.stall = 0;
+}
+__device__ __forceinline__ void inst_load(Inst &s, const Ws &W, int b) {
+  s.mu = W.mu[b]; s.rho = W.rho[b]; s.phi0 = W.phi0[b]; s.Dd = W.Dd[b]; s.fcur = W.fcur[b]; s.thcur = W.thcur[b];
+  s.logcur = W.logcur[b]; s.res_stat = W.res_stat[b]; s.res_eq = W.res_eq[b]; s.res_ineq = W.res_ineq[b];
+  s.res_comp = W.res_comp[b]; s.obj = W.obj[b];
+  s.amin_p = __longlong_as_double((long long)W.amin_p[b]); s.amin_d = __longlong_as_double((long long)W.amin_d[b]);
+  s.status = W.status[b]; s.iters = W.iters[b]; s.ls = W.ls[b]; s.ls0 = W.ls0[b]; s.lsst = W.lsst[b]; s.cur = W.cur[b];
+  s.newstep = W.newstep[b]; s.redo = W.redo[b]; s.force_gn = W.force_gn[b]; s.gn_sticky = W.gn_sticky[b];
+  s.curv_fail = W.curv_fail[b]; s.usedc = W.usedc[b]; s.stall = W.stall[b];
+}
+__device__ __forceinline__ void inst_store(const Inst &s, const Ws &W, int b) {
+  W.mu[b] = s.mu; W.rho[b] = s.rho; W.phi0[b] = s.phi0; W.Dd[b] = s.Dd; W.fcur[b] = s.fcur; W.thcur[b] = s.thcur;
+  W.logcur[b] = s.logcur; W.res_stat[b] = s.res_stat; W.res_eq[b] = s.res_eq; W.res_ineq[b] = s.res_ineq;
+  W.res_comp[b] = s.res_comp; W.obj[b] = s.obj;
+  W.amin_p[b] = (unsigned long long)__double_as_longlong(s.amin_p); W.amin_d[b] = (unsigned long long)__double_as_longlong(s.amin_d);
+  W.status[b] = s.status; W.iters[b] = s.iters; W.ls[b] = s.ls; W.ls0[b] = s.ls0; W.lsst[b] = s.lsst; W.cur[b] = s.cur;
+  W.newstep[b] = s.newstep; W.redo[b] = s.redo; W.force_gn[b] = s.force_gn; W.gn_sticky[b] = s.gn_sticky;
+  W.curv_fail[b] = s.curv_fail; W.usedc[b] = s.usedc; W.stall[b] = s.stall;
+}
+
+// whole-horizon sums / maxima of the trial point the last sweep evaluated (+ the merit slope of the step)
+struct Reduced { double f, th, lgs, rstat, req, rineq, rcomp, sumc, minc, badf, gphi; };
+
+// Armijo test of the trial point, acceptance, barrier update, convergence tests.  Returns true when a new
+// step has to be computed (Riccati recursion next; `usec`: with the exact constraint curvature); false when
+// the instance retries with a shorter step, re-evaluates (null pass) or has stopped (s.status).
+template <class C>
+__device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Reduced &r, const bool first, bool &usec) {
   const int N = M.N;
-  (void)B;
-
-  // ---- reduce the stage partials of the trial point --------------------------------
-  double f = 0, th = 0, lgs = 0, rstat = 0, req = 0, rineq = 0, rcomp = 0, sumc = 0, minc = 1e300, badf = 0, gphi = 0;
-  for (int k = lane; k < N; k += LPI) {
-    f += W.part[IDX(P_F, k, b)];
-    th += W.part[IDX(P_TH, k, b)];
-    lgs += W.part[IDX(P_LOGS, k, b)];
-    rstat = fmax(rstat, W.part[IDX(P_RSTAT, k, b)]);
-    req = fmax(req, W.part[IDX(P_REQ, k, b)]);
-    rineq = fmax(rineq, W.part[IDX(P_RINEQ, k, b)]);
-    rcomp = fmax(rcomp, W.part[IDX(P_RCOMP, k, b)]);
-    sumc += W.part[IDX(P_SUMC, k, b)];
-    minc = fmin(minc, W.part[IDX(P_MINC, k, b)]);
-    badf += W.part[IDX(P_BAD, k, b)];
-    gphi += first ? 0.0 : W.gphi[(size_t)k * W.Bp + b];
-  }
-  f = wave_sum<LPI>(f); th = wave_sum<LPI>(th); lgs = wave_sum<LPI>(lgs); sumc = wave_sum<LPI>(sumc); badf = wave_sum<LPI>(badf);
-  gphi = wave_sum<LPI>(gphi);
-  rstat = wave_max<LPI>(rstat); req = wave_max<LPI>(req); rineq = wave_max<LPI>(rineq); rcomp = wave_max<LPI>(rcomp);
-  minc = wave_min<LPI>(minc);
-
-  // ---- decisions: every lane computes them (identical values), lane 0 stores ---------
-  const bool L0 = (lane == 0);
-  if (L0) W.newstep[b] = 0;
-  double mu = W.mu[b];
+  s.newstep = 0;
+  double mu = s.mu;
   int status = ST_ACTIVE;
-  int iters = W.iters[b];
-  const bool redo = (!first) && (W.redo[b] != 0);
-  int lsst = first ? 0 : W.lsst[b];
+  int iters = s.iters;
+  const bool redo = (!first) && (s.redo != 0);
+  int lsst = first ? 0 : s.lsst;
+  usec = false;
   if (first) {
-    if (badf != 0.0) status = -7;  // inverse-barrier row not strictly feasible at the start
+    if (r.badf != 0.0) status = -7;  // inverse-barrier row not strictly feasible at the start
   } else if (redo) {
     // null pass: same point, the step is recomputed below with the Gauss-Newton blocks
-    if (L0) W.redo[b] = 0;
+    s.redo = 0;
   } else {
-    const double a0 = __longlong_as_double((long long)W.amin_p[b]);
-    int ls = W.ls[b];
-    double rho = W.rho[b], phi0 = W.phi0[b], Dd = W.Dd[b];
-    if (ls == W.ls0[b]) {   // first trial of this line search
-      const double thc = W.thcur[b];
+    const double a0 = s.amin_p;
+    int ls = s.ls;
+    double rho = s.rho, phi0 = s.phi0, Dd = s.Dd;
+    if (ls == s.ls0) {   // first trial of this line search
+      const double thc = s.thcur;
       if (thc > 1e-13) {
-        const double need = gphi / (0.9 * thc);
+        const double need = r.gphi / (0.9 * thc);
         if (rho < need) rho = need + 1.0;
       }
-      Dd = gphi - rho * thc;
-      phi0 = W.fcur[b] - mu * W.logcur[b] + rho * thc;
-      if (L0) { W.rho[b] = rho; W.phi0[b] = phi0; W.Dd[b] = Dd; }
+      Dd = r.gphi - rho * thc;
+      phi0 = s.fcur - mu * s.logcur + rho * thc;
+      s.rho = rho; s.phi0 = phi0; s.Dd = Dd;
     }
     const double alpha = ldexp(a0, -ls);
-    const double phi = f - mu * lgs + rho * th;
-    const bool ok = (badf == 0.0) && (phi <= phi0 + kArmijo * alpha * Dd + 1e-13 * fabs(phi0));
-    const int usedc = W.usedc[b];
+    const double phi = r.f - mu * r.lgs + rho * r.th;
+    const bool ok = (r.badf == 0.0) && (phi <= phi0 + kArmijo * alpha * Dd + 1e-13 * fabs(phi0));
+    const int usedc = s.usedc;
     if (!ok) {
       ls++;
       if (ls > (usedc ? kLsCurv - 1 : M.ls_max)) {
         if (usedc) {
           // the curvature step failed its line search: recompute this iteration's step with
           // the Gauss-Newton blocks (null pass next); latch after repeated failures
-          if (L0) {
-            const int cf = W.curv_fail[b] + 1;
-            W.curv_fail[b] = cf;
-            if (cf >= kCurvFailMax) W.gn_sticky[b] = 1;
-            W.redo[b] = 1;
-            W.force_gn[b] = 1;
-            W.ls[b] = 0;
-          }
-          return;
+          const int cf = s.curv_fail + 1;
+          s.curv_fail = cf;
+          if (cf >= kCurvFailMax) s.gn_sticky = 1;
+          s.redo = 1;
+          s.force_gn = 1;
+          s.ls = 0;
+          return false;
         }
-        if (L0) W.status[b] = -8;  // line search failure; the current iterate is returned
-        return;
+        s.status = -8;  // line search failure; the current iterate is returned
+        return false;
       }
-      if (L0) W.ls[b] = ls;
-      return;  // next sweep retries with alpha / 2
+      s.ls = ls;
+      return false;  // next sweep retries with alpha / 2
     }
-    if (usedc && L0) W.curv_fail[b] = 0;
+    if (usedc) s.curv_fail = 0;
     // step-length memory: the next Gauss-Newton line search starts one halving above the accepted one (models
     // whose steps overshoot every iteration -- the unicycle -- otherwise pay a pass per halving per iteration)
     lsst = ls > kLsGrow ? ls - kLsGrow : 0;
-    if (L0) W.lsst[b] = lsst;
+    s.lsst = lsst;
     iters++;
   }
   // ---- accept the trial point ------------------------------------------------------
   if (status == ST_ACTIVE) {
-    const double f_prev = W.fcur[b];
-    const int stall0 = W.stall[b];
-    __builtin_amdgcn_s_waitcnt(0);  // every lane has read the per-instance words before lane 0 rewrites them
-    if (L0) {
-      W.cur[b] ^= 1;
-      W.fcur[b] = f;
-      W.thcur[b] = th;
-      W.logcur[b] = lgs;
-    }
+    const double f_prev = s.fcur;
+    const int stall0 = s.stall;
+    s.cur ^= 1;
+    s.fcur = r.f;
+    s.thcur = r.th;
+    s.logcur = r.lgs;
     if (!redo) {
-      if (L0) {
-        W.iters[b] = iters;
-        W.res_stat[b] = rstat; W.res_eq[b] = req; W.res_ineq[b] = rineq; W.res_comp[b] = rcomp; W.obj[b] = f;
-      }
+      s.iters = iters;
+      s.res_stat = r.rstat; s.res_eq = r.req; s.res_ineq = r.rineq; s.res_comp = r.rcomp; s.obj = r.f;
       if (!first) {
         // LOQO-style centrality rule with floors (DESIGN.md, section "Algorithm")
         const double cnt = (double)N * (double)M.m;
-        const double avg = sumc / cnt;
-        const double xi = minc / avg;
+        const double avg = r.sumc / cnt;
+        const double xi = r.minc / avg;
         double sg = 0.05 * (1.0 - xi) / xi;
         if (sg > 2.0) sg = 2.0;
         sg = 0.1 * sg * sg * sg;
@@ -1003,21 +1024,21 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
         if (sg > 0.8) sg = 0.8;
         mu = sg * avg;
         if (mu < 0.1 * M.tol_comp) mu = 0.1 * M.tol_comp;
-        if (L0) W.mu[b] = mu;
+        s.mu = mu;
         if (!(mu < kMuDiverged)) status = -7;
       }
       if (status == ST_ACTIVE) {
-        if (!isfinite(rstat) || !isfinite(req) || !isfinite(rineq)) status = -6;
-        else if (rstat <= M.tol_stat && req <= M.tol_eq && rineq <= M.tol_ineq && rcomp <= M.tol_comp) status = 1;
+        if (!isfinite(r.rstat) || !isfinite(r.req) || !isfinite(r.rineq)) status = -6;
+        else if (r.rstat <= M.tol_stat && r.req <= M.tol_eq && r.rineq <= M.tol_ineq && r.rcomp <= M.tol_comp) status = 1;
         else {
           // acceptable termination: feasible, complementary, objective stagnant for acc_iters iterations
           int stall = stall0;
-          if (!first && req <= kAccFeas && rineq <= kAccFeas && rcomp <= kAccFeas &&
-              fabs(f - f_prev) <= M.acc_obj_tol * fmax(1.0, fabs(f)))
+          if (!first && r.req <= kAccFeas && r.rineq <= kAccFeas && r.rcomp <= kAccFeas &&
+              fabs(r.f - f_prev) <= M.acc_obj_tol * fmax(1.0, fabs(r.f)))
             stall++;
           else
             stall = 0;
-          if (L0) W.stall[b] = stall;
+          s.stall = stall;
           if (M.acc_iters > 0 && stall >= M.acc_iters) status = 2;
           else if (iters >= M.max_iter) status = 0;
         }
@@ -1025,31 +1046,69 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     }
   }
   if (status != ST_ACTIVE) {
-    if (L0) W.status[b] = status;
-    return;
+    s.status = status;
+    return false;
   }
   // exact constraint curvature unless latched off or this is the fallback pass
-  bool usec = false;
-  if constexpr (C::CURV) usec = M.use_curv && !W.gn_sticky[b] && !W.force_gn[b] && (mu <= kCurvMu);
-  __builtin_amdgcn_s_waitcnt(0);
-  if (L0) {
-    W.force_gn[b] = 0;
-    // a step with the exact curvature is tried at full length first
-    const int lsb = usec ? 0 : lsst;
-    W.ls[b] = lsb;
-    W.ls0[b] = lsb;
+  if constexpr (C::CURV) usec = M.use_curv && !s.gn_sticky && !s.force_gn && (mu <= kCurvMu);
+  s.force_gn = 0;
+  // a step with the exact curvature is tried at full length first
+  const int lsb = usec ? 0 : lsst;
+  s.ls = lsb;
+  s.ls0 = lsb;
+  return true;
+}
+// after the recursion: a failed factorisation either falls back to Gauss-Newton (null pass) or stops the instance
+__device__ __forceinline__ void inst_after_recursion(Inst &s, const bool chol_ok, const bool usec) {
+  if (!chol_ok) {
+    if (usec) {
+      // reduced Hessian not positive definite with the curvature terms: recompute this
+      // iteration's step with the Gauss-Newton blocks (null pass next); not counted as a
+      // line-search failure
+      s.redo = 1; s.force_gn = 1; s.usedc = 0;
+      return;
+    }
+    s.status = -5;
+    return;
   }
-  const double cwt = usec ? 1.0 : 0.0;  // Cqq is zero-filled when the model does not use it
+  s.usedc = usec ? 1 : 0;
+  s.newstep = 1;
+  s.amin_p = 1.0;   // the step kernel takes the minima next
+  s.amin_d = 1.0;
+}
 
+// where the recursion leaves the step: dz[slot * SS + k * KS], nunew likewise (pointers advanced to the instance)
+struct StepOut {
+  double *dz, *nunew;
+  size_t SS, KS;
+};
+
+template <class C, int LPI>
+struct RicLds {
+  static constexpr int NX = C::NX, NV = C::NV, NW = C::NW;
+  static constexpr int NP2 = NX * (NX + 1) / 2;
+  static constexpr int KPW = NW * NX + NW + NP2 + NX + NX;
+  static constexpr int LDSW = KPW + NX * NX + NX * NV + NV * NV + NV + NX * NV + NX + NX + NW + C::RS;   // doubles per instance
+};
+
+// Block-tridiagonal Riccati recursion of one instance, LPI lanes.  img: the instance's LDS row (RicLds::LDSW
+// doubles); rb: its stage records (stage 0, stride C::RS; global memory or LDS); kpb: its gain records (stride
+// kps, global memory).  Returns false when a stage's control block is not positive definite.
+template <class C, int LPI>
+__device__ __forceinline__ bool riccati_recursion(const DevModel &M, const double mu, const bool usec, const int lane,
+                                                  double *const img, const double *const rb, double *const kpb,
+                                                  const int kps, const StepOut so) {
+  constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NV = C::NV, NW = C::NW;
+  constexpr bool DD = (C::ROBOT == RMPC_ROBOT_DIFFDRIVE);
+  const int N = M.N;
+  const double cwt = usec ? 1.0 : 0.0;  // Cqq is zero-filled when the model does not use it
   // ---- LDS images -------------------------------------------------------------------------
   // img = [K | kff | P (upper triangle) | p | rc]: what the forward pass needs of a stage, contiguous in
   // LDS so that it leaves for (and returns from) the instance's gain record KP in one request
   constexpr int NP2 = NX * (NX + 1) / 2;
   constexpr int KPW = NW * NX + NW + NP2 + NX + NX;
   constexpr int KPL = (KPW + LPI - 1) / LPI;
-  constexpr int LDSW = KPW + NX * NX + NX * NV + NV * NV + NV + NX * NV + NX + NX + NW + C::RS;
-  __shared__ double lds[IPB * IPW][LDSW];
-  double *const img = lds[wv], *const sK = img, *const skf = sK + NW * NX, *const sPt = skf + NW, *const sp = sPt + NP2,
+  double *const sK = img, *const skf = sK + NW * NX, *const sPt = skf + NW, *const sp = sPt + NP2,
                *const src = sp + NX, *const sP = img + KPW, *const sAB = sP + NX * NX, *const sQ = sAB + NX * NV,
                *const sq = sQ + NV * NV, *const sT = sq + NV, *const sPc = sT + NX * NV, *const sdx = sPc + NX,
                *const sdw = sdx + NX, *const srec = sdw + NW;   // srec: the stage record as fetched
@@ -1065,7 +1124,6 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   // records (stage 0; an entry of the record, or its zero slot) plus a constant.  The per-stage fetch
   // is then an unconditional load per entry -- no branch around any load -- and all lanes of the
   // wavefront address the same few cache lines.
-  const double *const rb = W.R + (size_t)b * N * C::RS;   // stage 0 record of this instance
   const double *const zer = rb + C::R_ZERO;
   constexpr size_t sstr = (size_t)C::RS;                  // stage stride of the records
   constexpr int EPL = (NV * NV + LPI - 1) / LPI;   // stage Hessian entries per lane
@@ -1156,7 +1214,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     if (k > 0) fetch_stage(k - 1);  // travels while this stage is computed
     WSYNC();
     if (k < N - 1) {
-      double *const kp1 = W.KP + ((size_t)b * N + (k + 1)) * W.kps;
+      double *const kp1 = kpb + (size_t)(k + 1) * kps;
 #pragma unroll
       for (int u = 0; u < KPL; u++) {
         const int e = lane + LPI * u;
@@ -1342,30 +1400,18 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     }
     // (the fill of the next stage touches sQ / sq / src only; its barrier orders the sP writes)
   }
-  if (!chol_ok) {
-    if (usec) {
-      // reduced Hessian not positive definite with the curvature terms: recompute this
-      // iteration's step with the Gauss-Newton blocks (null pass next); not counted as a
-      // line-search failure
-      if (L0) { W.redo[b] = 1; W.force_gn[b] = 1; W.usedc[b] = 0; }
-      return;
-    }
-    if (L0) W.status[b] = -5;
-    return;
-  }
-  if (L0) W.usedc[b] = usec ? 1 : 0;
+  if (!chol_ok) return false;
 
   // ---- forward rollout + costates nu+_k = P_k dx_k + p_k ------------------------------------------
   // the image of stage 0 is still in LDS; later stages come back from the gain record (one request each)
   WSYNC();
   if (lane < NX) sdx[lane] = 0.0;
   double fv[KPL];
-  const double *const kpb = W.KP + (size_t)b * N * W.kps;
   auto fetch_fwd = [&](int k) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < KPL; u++) {
       const int e = lane + LPI * u;
-      fv[u] = kpb[(size_t)k * W.kps + (e < KPW ? e : 0)];
+      fv[u] = kpb[(size_t)k * kps + (e < KPW ? e : 0)];
     }
   };
   if (N > 1) fetch_fwd(1);
@@ -1404,11 +1450,11 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
         dzv = s;
       } else {
         dzv = sdx[i];
-        if (k >= 1) W.nunew[IDX(i, k, b)] = s;
+        if (k >= 1) so.nunew[(size_t)i * so.SS + (size_t)k * so.KS] = s;
       }
     }
     // dz of the stage in one request: lanes < NW hold dw (slots NX..), the next NX lanes dx (slots 0..)
-    if (lane < NW + NX) W.dz[IDX(lane < NW ? NX + lane : lane - NW, k, b)] = dzv;
+    if (lane < NW + NX) so.dz[(size_t)(lane < NW ? NX + lane : lane - NW) * so.SS + (size_t)k * so.KS] = dzv;
     WSYNC();
     double dxn = 0.0;
     if (k < N - 1 && lane < NX) {
@@ -1434,40 +1480,102 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     if (k < N - 1 && lane < NX) sdx[lane] = dxn;
     // (next iteration's barrier orders this write before the reads)
   }
-  if (L0) {
-    W.newstep[b] = 1;
-    W.amin_p[b] = (unsigned long long)__double_as_longlong(1.0);  // k_step takes the minima next
-    W.amin_d[b] = (unsigned long long)__double_as_longlong(1.0);
+  return true;
+}
+
+template <class C, int IPB>
+__global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel M, const Ws W, const int B, const int first,
+                                                const int pass) {
+  // IPB wavefronts per block work on IPB consecutive list entries: neighbouring instances share
+  // the 128-byte lines of the batch-minor arrays, so most of a wave's requests hit the CU's L1
+  // Two instantiations are launched every pass and pick their regime from the list length:
+  // the grouped one (IPB = C::IPB) while many instances iterate, the one-wave blocks (IPB = 1,
+  // static LDS addresses, lowest latency) in the iteration tail.
+  const int nact = *W.n_act;
+  if constexpr (C::IPB > 1) {
+    if ((IPB > 1) != (nact >= kGroupedMin)) return;
   }
+  // lanes per instance: a whole wavefront, or half of one in the grouped regime of the small models (their
+  // dense blocks have few rows: two instances per wavefront halve the LDS instructions an instance costs, and
+  // LDS instruction throughput is what bounds this kernel when the whole batch iterates)
+  constexpr int LPI = (IPB > 1) ? C::RIC_LPI : 64;
+  constexpr int IPW = 64 / LPI;
+  const int wv = threadIdx.x / LPI;   // instance slot within the block
+  const int li = blockIdx.x * (IPB * IPW) + wv;
+  if (li >= nact) return;
+  const int b = W.act_idx[li];
+  if (W.status[b] != ST_ACTIVE) return;  // uniform over the lanes of an instance (whole wavefront, or one half in the grouped regime)
+  const int lane = threadIdx.x & (LPI - 1);
+  const int N = M.N;
+  (void)B; (void)pass;
+
+  // ---- reduce the stage partials of the trial point --------------------------------
+  Reduced r = {0, 0, 0, 0, 0, 0, 0, 0, 1e300, 0, 0};
+  for (int k = lane; k < N; k += LPI) {
+    r.f += W.part[IDX(P_F, k, b)];
+    r.th += W.part[IDX(P_TH, k, b)];
+    r.lgs += W.part[IDX(P_LOGS, k, b)];
+    r.rstat = fmax(r.rstat, W.part[IDX(P_RSTAT, k, b)]);
+    r.req = fmax(r.req, W.part[IDX(P_REQ, k, b)]);
+    r.rineq = fmax(r.rineq, W.part[IDX(P_RINEQ, k, b)]);
+    r.rcomp = fmax(r.rcomp, W.part[IDX(P_RCOMP, k, b)]);
+    r.sumc += W.part[IDX(P_SUMC, k, b)];
+    r.minc = fmin(r.minc, W.part[IDX(P_MINC, k, b)]);
+    r.badf += W.part[IDX(P_BAD, k, b)];
+    r.gphi += first ? 0.0 : W.gphi[(size_t)k * W.Bp + b];
+  }
+  r.f = wave_sum<LPI>(r.f); r.th = wave_sum<LPI>(r.th); r.lgs = wave_sum<LPI>(r.lgs); r.sumc = wave_sum<LPI>(r.sumc);
+  r.badf = wave_sum<LPI>(r.badf); r.gphi = wave_sum<LPI>(r.gphi);
+  r.rstat = wave_max<LPI>(r.rstat); r.req = wave_max<LPI>(r.req); r.rineq = wave_max<LPI>(r.rineq); r.rcomp = wave_max<LPI>(r.rcomp);
+  r.minc = wave_min<LPI>(r.minc);
+
+  // ---- decisions: every lane computes them (identical values), lane 0 stores ---------
+  const bool L0 = (lane == 0);
+  Inst s;
+  inst_load(s, W, b);
+  bool usec = false;
+  const bool recurse = inst_decide<C>(M, s, r, first != 0, usec);
+  if (!recurse) {
+    if (L0) inst_store(s, W, b);
+    return;
+  }
+  __shared__ double lds[IPB * IPW][RicLds<C, LPI>::LDSW];
+  StepOut so;
+  so.dz = W.dz + b; so.nunew = W.nunew + b; so.SS = (size_t)N * W.Bp; so.KS = (size_t)W.Bp;
+  const bool chol_ok = riccati_recursion<C, LPI>(M, s.mu, usec, lane, lds[wv], W.R + (size_t)b * N * C::RS,
+                                                 W.KP + (size_t)b * N * W.kps, W.kps, so);
+  inst_after_recursion(s, chol_ok, usec);
+  if (L0) inst_store(s, W, b);
 }
 
 // ===========================================================================
 // k_step: slack / multiplier steps and step-length partials, stage parallel
 // ===========================================================================
+// What one lane of the step kernel addresses (same convention as SweepIO).
+struct StepIO {
+  const double *zc, *tc, *lc, *grow, *Jq, *dz, *gfa;
+  size_t SS;
+  unsigned loff;
+};
+
+// ap, ad: fraction-to-the-boundary step lengths of this stage (1 when no row binds); gphi: its merit slope partial
 template <class C>
-__global__ __launch_bounds__(kSweepBlock) void k_step(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
-                                              const int B) {
+__device__ __forceinline__ void step_body(const DevTables &T, const StepIO &io, const int k, const double mu,
+                                          double &ap_out, double &ad_out, double &gphi_out) {
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NV = C::NV;
-  const DevTables &T = *Tp;
-  const int gid = blockIdx.x * kSweepBlock + threadIdx.x;
-  const int li = gid % W.Bp;
-  const int k = gid / W.Bp;
-  if (li >= *W.n_act || k >= M.N) return;
-  const int b = W.act_idx[li];
-  if (W.status[b] != ST_ACTIVE || !W.newstep[b]) return;
-  const int cur = W.cur[b];
-  const double *__restrict__ zc = W.z[cur];
-  const double *__restrict__ tc = W.t[cur];
-  const double *__restrict__ lc = W.lam[cur];
-  const double *__restrict__ grow = W.grow[cur];
-  const double *__restrict__ Jq = W.Jq[cur];
-  const double mu = W.mu[b];
+  const unsigned loff = io.loff;
+  const size_t SS = io.SS;
+  const double *__restrict__ zc = io.zc;
+  const double *__restrict__ tc = io.tc;
+  const double *__restrict__ lc = io.lc;
+  const double *__restrict__ grow = io.grow;
+  const double *__restrict__ Jq = io.Jq;
   double dz[NV], z[NV], gfv[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) {
-    dz[j] = W.dz[IDX(j, k, b)];
-    z[j] = zc[IDX(j, k, b)];
-    gfv[j] = W.gfa[IDX(j, k, b)];
+    dz[j] = io.dz[IDXL(j)];
+    z[j] = zc[IDXL(j)];
+    gfv[j] = io.gfa[IDXL(j)];
   }
   double gphi = 0.0;
 #pragma unroll
@@ -1476,8 +1584,8 @@ __global__ __launch_bounds__(kSweepBlock) void k_step(const DevModel M, const De
   auto row = [&](int i, double gdz, double g, double tv, double lv) __attribute__((always_inline)) {
     const double dt = gdz + (g - tv);
     const double itv = frcp(tv);
-    const double dl = (mu - tv * lv - lv * dt) * itv;   // (same expression as in k_sweep's row_core)
-    (void)i;  // the steps themselves are not stored: k_sweep recomputes them from the same inputs
+    const double dl = (mu - tv * lv - lv * dt) * itv;   // (same expression as in sweep_body's row_core)
+    (void)i;  // the steps themselves are not stored: the sweep recomputes them from the same inputs
     // ratio tests with Newton reciprocals (the quotient of a non-negative step is discarded by the select)
     const double rp = -kTau * tv * frcp(dt), rd = -kTau * lv * frcp(dl);
     ap = (dt < 0 && rp < ap) ? rp : ap;
@@ -1487,17 +1595,17 @@ __global__ __launch_bounds__(kSweepBlock) void k_step(const DevModel M, const De
   // FK rows
   for (int r = 0; r < T.nfkrows; r++) {
     const int i = T.fk_row[r], fi = T.fk_idx[r];
-    const double g = grow[IDX(i, k, b)], tv = tc[IDX(i, k, b)], lv = lc[IDX(i, k, b)];
+    const double g = grow[IDXL(i)], tv = tc[IDXL(i)], lv = lc[IDXL(i)];
     double jq[NQ];
 #pragma unroll
-    for (int a = 0; a < NQ; a++) jq[a] = Jq[IDX(fi * NQ + a, k, b)];
+    for (int a = 0; a < NQ; a++) jq[a] = Jq[IDXL(fi * NQ + a)];
     double gdz = 0.0;
 #pragma unroll
     for (int a = 0; a < NQ; a++) gdz += jq[a] * dz[a];
     if constexpr (NS > 0) gdz += dz[NX];
     row(i, gdz, g, tv, lv);
   }
-  // single-variable rows, by variable (unconditional clamped requests, see k_sweep)
+  // single-variable rows, by variable (unconditional clamped requests, see sweep_body)
 #pragma unroll
   for (int j = 0; j < NV; j++) {
     double tv[kVarRows], lv[kVarRows], gv[kVarRows];
@@ -1506,9 +1614,9 @@ __global__ __launch_bounds__(kSweepBlock) void k_step(const DevModel M, const De
       const int i = T.v_row[j][u];
       const int ii = i >= 0 ? i : 0;
       const bool general = T.v_poff[j][u] >= 0;
-      tv[u] = tc[IDX(ii, k, b)];
-      lv[u] = lc[IDX(ii, k, b)];
-      const double gl = grow[IDX(general ? ii : 0, k, b)];
+      tv[u] = tc[IDXL(ii)];
+      lv[u] = lc[IDXL(ii)];
+      const double gl = grow[IDXL(general ? ii : 0)];
       gv[u] = general ? gl : ((k == 0 && j < NX) ? 1.0 : (double)T.v_sgn[j][u] * (z[j] - T.v_val[j][u]));
     }
 #pragma unroll
@@ -1520,6 +1628,27 @@ __global__ __launch_bounds__(kSweepBlock) void k_step(const DevModel M, const De
       row(i, gdz, gv[u], tv[u], lv[u]);
     }
   }
+  ap_out = ap; ad_out = ad; gphi_out = gphi;
+}
+
+template <class C>
+__global__ __launch_bounds__(kSweepBlock) void k_step(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
+                                              const int B) {
+  const int gid = blockIdx.x * kSweepBlock + threadIdx.x;
+  const int li = gid % W.Bp;
+  const int k = gid / W.Bp;
+  if (li >= *W.n_act || k >= M.N) return;
+  const int b = W.act_idx[li];
+  if (W.status[b] != ST_ACTIVE || !W.newstep[b]) return;
+  (void)B;
+  const int cur = W.cur[b];
+  StepIO io;
+  io.zc = W.z[cur]; io.tc = W.t[cur]; io.lc = W.lam[cur]; io.grow = W.grow[cur]; io.Jq = W.Jq[cur];
+  io.dz = W.dz; io.gfa = W.gfa;
+  io.SS = (size_t)M.N * W.Bp;
+  io.loff = (unsigned)k * (unsigned)W.Bp + (unsigned)b;
+  double ap, ad, gphi;
+  step_body<C>(*Tp, io, k, W.mu[b], ap, ad, gphi);
   // partial minima -> per-instance step lengths (min is order independent: deterministic)
   atomicMin(&W.amin_p[b], (unsigned long long)__double_as_longlong(ap));
   atomicMin(&W.amin_d[b], (unsigned long long)__double_as_longlong(ad));
