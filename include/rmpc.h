@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RMPC_VERSION 101 /* 0.1.1: rmpc_desc.ls_max */
+#define RMPC_VERSION 102 /* 0.1.2: rmpc_source_hash, fused kernel in the profile (RMPC_NUM_KERNELS 6) */
 
 #define RMPC_MAX_JOINTS 8
 #define RMPC_MAX_LINKS 8
@@ -141,8 +141,9 @@ int rmpc_solve_batch_device(rmpc_handle *h, int B, const double *d_xinit,
 int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch);
 
 /* Per-kernel timing with HIP events on the solver's stream.
- * kernels: 0 pack, 1 sweep, 2 riccati, 3 step, 4 unpack. */
-#define RMPC_NUM_KERNELS 5
+ * kernels: 0 pack, 1 sweep, 2 riccati, 3 step, 4 unpack (pass kernels: large horizons, the arm),
+ * 5 fused (whole solves inside one wavefront: point robot and diff-drive base, N <= 32). */
+#define RMPC_NUM_KERNELS 6
 int rmpc_set_profiling(rmpc_handle *h, int enable);
 /* total_ms / launches: summed HIP-event durations and launch counts per kernel;
  * total_alg_bytes: algorithmic bytes of those launches, counting only the lanes
@@ -209,6 +210,10 @@ int rmpc_free_space_device(int B, int N, int P, int K, double max_radius, const 
 int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x0,
                      const double *params, double *out_Q, double *out_q0,
                      double *out_q1, double *out_rc, double *out_g, double *out_f);
+
+/* Development aid: per-block phase cycle counts of the last fused launch (8 words per block: sweep, decisions,
+ * recursion, step, total, passes, start, -); all zero unless the library was built with -DRMPC_STAMPS. */
+int rmpc_debug_fused_stamps(rmpc_handle *h, long long *out, int nblocks);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RMPC_LIB_PATH") or os.path.join(_HERE, "csrc", "librmpc_hip.so")
 
 MAX_JOINTS, MAX_LINKS, MAX_PAIRS, MAX_MODULES, NV_MAX = 8, 8, 4, 8, 24
-NUM_KERNELS = 5
+NUM_KERNELS = 6
 
 
 class RmpcError(RuntimeError):
@@ -72,7 +72,7 @@ EXPORTED_SYMBOLS = [
     "rmpc_version", "rmpc_source_hash", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
     "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_profiling", "rmpc_get_profile",
     "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep",
-    "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_advance_device", "rmpc_free_space_device",
+    "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_advance_device", "rmpc_free_space_device",
 ]
 
 _lib = None
@@ -140,6 +140,8 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_last_passes.argtypes = [C.c_void_p]
     L.rmpc_debug_sweep.restype = C.c_int
     L.rmpc_debug_sweep.argtypes = [C.c_void_p, C.c_int] + [dp] * 9
+    L.rmpc_debug_fused_stamps.restype = C.c_int
+    L.rmpc_debug_fused_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
     L.rmpc_pack_scene_device.restype = C.c_int
     L.rmpc_pack_scene_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(RmpcScene), C.c_void_p, C.c_void_p]
     L.rmpc_solve_batch_scene_device.restype = C.c_int
@@ -345,6 +347,12 @@ class Solver:
         return {self._L.rmpc_kernel_name(i).decode(): dict(total_ms=ms[i], launches=n[i], total_alg_bytes=by[i],
                                                            full_launch_bytes=full[i])
                 for i in range(NUM_KERNELS)}
+
+    def fused_stamps(self, nblocks: int):
+        out = np.zeros((nblocks, 8), dtype=np.int64)
+        self._check(self._L.rmpc_debug_fused_stamps(self._h, out.ctypes.data_as(C.POINTER(C.c_longlong)), nblocks),
+                    "rmpc_debug_fused_stamps")
+        return out
 
     def last_passes(self) -> int:
         return int(self._L.rmpc_last_passes(self._h))

@@ -63,6 +63,12 @@ enum Status : int { ST_ACTIVE = 100 };
 
 enum Part : int { P_F = 0, P_TH, P_LOGS, P_RSTAT, P_REQ, P_RINEQ, P_RCOMP, P_SUMC, P_MINC, P_BAD, P_COUNT };
 
+// Explicit address spaces for what the fused kernel addresses: pointers that travel through structs or are
+// selected at run time are otherwise compiled to FLAT accesses, which count on both memory counters and so
+// serialise global-memory and LDS waits.
+typedef __attribute__((address_space(1))) double gdouble;   // global memory
+typedef __attribute__((address_space(3))) double ldouble;   // LDS
+
 // Device workspace (all pointers into one allocation).
 struct Ws {
   int N, Bp;
@@ -303,57 +309,62 @@ __device__ __forceinline__ void for_range(F &&fn) {
 // array is ptr[slot * SS + loff]: the batch-minor SoA of the pass kernels (SS = N * Bp, loff = k * Bp + b,
 // next stage kstride = Bp) and the per-instance layout of the fused kernel ([instance][slot][32 stages]:
 // SS = 32, loff = k, kstride = 1, pointers advanced to the instance) run the same code.
+template <class RP = gdouble>   // RP: where the stage record and the step live (gdouble, or ldouble in the fused kernel)
 struct SweepIO {
-  const double *zc, *tc, *lc, *nc, *pp, *dzp, *gro, *jqo, *nup;   // iterate (current buffer), parameters, step
-  double *zn, *tn, *ln, *nn, *grn, *jqn, *gfa;                    // trial point (other buffer), cost gradient
-  double *rec;                                                     // this lane's stage record
+  const gdouble *zc, *tc, *lc, *nc, *pp, *gro, *jqo;   // iterate (current buffer), parameters
+  gdouble *zn, *tn, *ln, *nn, *grn, *jqn, *gfa;        // trial point (other buffer), cost gradient
+  const RP *dzp, *nup;                                 // step
+  RP *rec;                                             // this lane's stage record
   size_t SS;
   unsigned loff, kstride;
+  // the step (dzp, nup) may live elsewhere (fused kernel: in the LDS slots of the instance): own strides
+  size_t SSd;
+  unsigned loffd, kstrided;
 };
 // merit / KKT partial sums of one stage (order = enum Part)
 struct Partials { double f, th, logs, rstat, req, rineq, rcomp, sumc, minc, bad; };
 
-template <class C>
-__device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T, const SweepIO &io, const int k,
+template <class C, int EARLY_MODE = -1, class RP = gdouble>
+__device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T, const SweepIO<RP> &io, const int k,
                                            const bool first, const bool nostep, const double alpha, const double adual,
                                            const double mu, Partials &out) {
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV;
   const int N = M.N;
   const unsigned loff = io.loff;
   const size_t SS = io.SS;
-  const double *__restrict__ zc = io.zc;
-  const double *__restrict__ tc = io.tc;
-  const double *__restrict__ lc = io.lc;
-  const double *__restrict__ nc = io.nc;
-  double *__restrict__ zn = io.zn;
-  double *__restrict__ tn = io.tn;
-  double *__restrict__ ln = io.ln;
-  double *__restrict__ nn = io.nn;
-  const double *__restrict__ pp = io.pp;
-  const double *__restrict__ dzp = io.dzp;
-  const double *__restrict__ gro = io.gro;   // row values and FK-row gradients at the current iterate:
-  const double *__restrict__ jqo = io.jqo;   //  the slack / multiplier steps are recomputed from them
-  double *__restrict__ grn = io.grn;
-  double *__restrict__ jqn = io.jqn;
-  const double *__restrict__ nup = io.nup;
-  double *__restrict__ gfa = io.gfa;
-  double *__restrict__ rec = (double *)__builtin_assume_aligned(io.rec, 64);   // 64-byte aligned: neighbouring entries leave as 16-byte stores
-  const double am = nostep ? 0.0 : alpha;   // multiplies the steps (0 on first / null passes:
-  const double dm = nostep ? 0.0 : adual;   //  the steps are stale but finite)
+  const gdouble *__restrict__ zc = io.zc;
+  const gdouble *__restrict__ tc = io.tc;
+  const gdouble *__restrict__ lc = io.lc;
+  const gdouble *__restrict__ nc = io.nc;
+  gdouble *__restrict__ zn = io.zn;
+  gdouble *__restrict__ tn = io.tn;
+  gdouble *__restrict__ ln = io.ln;
+  gdouble *__restrict__ nn = io.nn;
+  const gdouble *__restrict__ pp = io.pp;
+  const RP *__restrict__ dzp = io.dzp;
+  const gdouble *__restrict__ gro = io.gro;   // row values and FK-row gradients at the current iterate:
+  const gdouble *__restrict__ jqo = io.jqo;   //  the slack / multiplier steps are recomputed from them
+  gdouble *__restrict__ grn = io.grn;
+  gdouble *__restrict__ jqn = io.jqn;
+  const RP *__restrict__ nup = io.nup;
+  gdouble *__restrict__ gfa = io.gfa;
+  RP *__restrict__ rec = (RP *)__builtin_assume_aligned(io.rec, 64);   // 64-byte aligned: neighbouring entries leave as 16-byte stores
 
   // ---- trial stage vector, costates, next stage's state ------------------------
   double z[NV], xk1[NX], nuk[NX], nun[NX];
   double zo[NV], dzo[NV];   // current iterate and step of this stage (the row steps are recomputed from them)
   {
-#pragma unroll
-    for (int j = 0; j < NV; j++) { zo[j] = zc[IDXL(j)]; dzo[j] = dzp[IDXL(j)]; }
     const unsigned loff1 = loff + (k < N - 1 ? io.kstride : 0u);  // next stage, clamped: loads stay unconditional
+    const size_t SSd = io.SSd;
+    const unsigned loffd = io.loffd, loffd1 = io.loffd + (k < N - 1 ? io.kstrided : 0u);
+#pragma unroll
+    for (int j = 0; j < NV; j++) { zo[j] = zc[IDXL(j)]; dzo[j] = dzp[(size_t)j * SSd + loffd]; }
     double x1[NX], dx1[NX], n0[NX], n0n[NX], n1[NX], n1n[NX];
 #pragma unroll
     for (int j = 0; j < NX; j++) {
-      x1[j] = zc[IDXL1(j)]; dx1[j] = dzp[IDXL1(j)];
-      n0[j] = nc[IDXL(j)];  n0n[j] = nup[IDXL(j)];
-      n1[j] = nc[IDXL1(j)]; n1n[j] = nup[IDXL1(j)];
+      x1[j] = zc[IDXL1(j)]; dx1[j] = dzp[(size_t)j * SSd + loffd1];
+      n0[j] = nc[IDXL(j)];  n0n[j] = nup[(size_t)j * SSd + loffd];
+      n1[j] = nc[IDXL1(j)]; n1n[j] = nup[(size_t)j * SSd + loffd1];
     }
 #pragma unroll
     for (int j = 0; j < NV; j++) {
@@ -425,8 +436,10 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
     } else {
       const double dtv = gdz + (gold - tcv);
       const double dlv = (mu - tcv * lcv - lcv * dtv) * frcp(tcv);
-      tv = tcv + am * dtv;
-      lv = lcv + dm * dlv;
+      // (null passes keep the point by selection, not by a zero step length: the step they would multiply
+      //  may be stale -- after a failed factorisation of the fused kernel even non-finite)
+      tv = nostep ? tcv : tcv + alpha * dtv;
+      lv = nostep ? lcv : lcv + adual * dlv;
     }
     tn[IDXL(i)] = tv;
     ln[IDXL(i)] = lv;
@@ -538,7 +551,7 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
   // The arm: velocity and input variables first, so that their accumulators are dead before the kinematics
   // start (the slack variable collects from every softened row and waits for the end): 1.2 KB less scratch
   // per lane, sweep 190 -> 139 us on cfg4.  The three-joint models do not spill and lose 7 % this way.
-  constexpr bool EARLY = CHAIN && (NQ > 3);
+  constexpr bool EARLY = (EARLY_MODE >= 0) ? (CHAIN && EARLY_MODE != 0) : (CHAIN && (NQ > 3));
   if constexpr (EARLY) {
     for_range<NQ, NV>([&](auto jc) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
@@ -804,16 +817,18 @@ __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevMo
   const int N = M.N;
   (void)B;
   const int cur = W.cur[b], nxt = cur ^ 1;
-  SweepIO io;
-  io.zc = W.z[cur]; io.tc = W.t[cur]; io.lc = W.lam[cur]; io.nc = W.nu[cur];
-  io.zn = W.z[nxt]; io.tn = W.t[nxt]; io.ln = W.lam[nxt]; io.nn = W.nu[nxt];
-  io.pp = W.p; io.dzp = W.dz; io.gro = W.grow[cur]; io.jqo = W.Jq[cur]; io.grn = W.grow[nxt]; io.jqn = W.Jq[nxt];
-  io.nup = W.nunew; io.gfa = W.gfa;
-  io.rec = W.R + ((size_t)b * N + k) * C::RS;   // this lane's stage record
+  SweepIO<gdouble> io;
+  io.zc = (gdouble *)W.z[cur]; io.tc = (gdouble *)W.t[cur]; io.lc = (gdouble *)W.lam[cur]; io.nc = (gdouble *)W.nu[cur];
+  io.zn = (gdouble *)W.z[nxt]; io.tn = (gdouble *)W.t[nxt]; io.ln = (gdouble *)W.lam[nxt]; io.nn = (gdouble *)W.nu[nxt];
+  io.pp = (gdouble *)W.p; io.dzp = (gdouble *)W.dz; io.gro = (gdouble *)W.grow[cur]; io.jqo = (gdouble *)W.Jq[cur];
+  io.grn = (gdouble *)W.grow[nxt]; io.jqn = (gdouble *)W.Jq[nxt];
+  io.nup = (gdouble *)W.nunew; io.gfa = (gdouble *)W.gfa;
+  io.rec = (gdouble *)(W.R + ((size_t)b * N + k) * C::RS);   // this lane's stage record
   // element offset of this lane inside a slot (32-bit, so that accesses become uniform base + lane offset) and slot size
   io.loff = (unsigned)k * (unsigned)W.Bp + (unsigned)b;
   io.kstride = (unsigned)W.Bp;
   io.SS = (size_t)N * W.Bp;
+  io.SSd = io.SS; io.loffd = io.loff; io.kstrided = io.kstride;
   // ---- step lengths of this trial --------------------------------------
   // null pass: the current point is re-evaluated unchanged so that the step can be
   // recomputed with the Gauss-Newton blocks (fallback of a failed curvature step)
@@ -1078,8 +1093,9 @@ __device__ __forceinline__ void inst_after_recursion(Inst &s, const bool chol_ok
 }
 
 // where the recursion leaves the step: dz[slot * SS + k * KS], nunew likewise (pointers advanced to the instance)
+template <class RP = gdouble>
 struct StepOut {
-  double *dz, *nunew;
+  RP *dz, *nunew;
   size_t SS, KS;
 };
 
@@ -1094,10 +1110,25 @@ struct RicLds {
 // Block-tridiagonal Riccati recursion of one instance, LPI lanes.  img: the instance's LDS row (RicLds::LDSW
 // doubles); rb: its stage records (stage 0, stride C::RS; global memory or LDS); kpb: its gain records (stride
 // kps, global memory).  Returns false when a stage's control block is not positive definite.
-template <class C, int LPI>
+// Fused kernel, small models: everything the recursion exchanges stays in LDS.  An instance owns 32 slots of
+// GS doubles, one per stage; slot k holds, in turn, the stage record the sweep wrote ([0, RW]), the gain image
+// of the stage that the backward pass leaves for the forward pass ([0, KPW): the record is dead by then), and
+// the step of the stage (dz | nu+ at [DZ_OFF, DZ_OFF + NV + NX): behind the record, so that the next sweeps
+// read the step while they write their records).
+template <class C>
+struct FusedSlots {
+  static constexpr int KPW = RicLds<C, 32>::KPW;
+  static constexpr int DZ_OFF = C::RW + 1;
+  static constexpr int NEED = (KPW > DZ_OFF + C::NV + C::NX) ? KPW : DZ_OFF + C::NV + C::NX;
+  static constexpr int GS = (NEED + 7) / 8 * 8;   // 64-byte slots: the sweep stores its record with aligned 16-byte writes
+};
+
+template <class C, int LPI, bool SLOTS = false, class RP = gdouble>
 __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const double mu, const bool usec, const int lane,
-                                                  double *const img, const double *const rb, double *const kpb,
-                                                  const int kps, const StepOut so) {
+                                                  ldouble *const img, const RP *const rb, gdouble *const kpb,
+                                                  const int kps, const StepOut<RP> so, ldouble *const slots = nullptr) {
+  // SLOTS: rb == slots (records), gains go to the slots as well (kpb unused)
+  constexpr int GS = FusedSlots<C>::GS;
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NV = C::NV, NW = C::NW;
   constexpr bool DD = (C::ROBOT == RMPC_ROBOT_DIFFDRIVE);
   const int N = M.N;
@@ -1108,7 +1139,7 @@ __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const doubl
   constexpr int NP2 = NX * (NX + 1) / 2;
   constexpr int KPW = NW * NX + NW + NP2 + NX + NX;
   constexpr int KPL = (KPW + LPI - 1) / LPI;
-  double *const sK = img, *const skf = sK + NW * NX, *const sPt = skf + NW, *const sp = sPt + NP2,
+  ldouble *const sK = img, *const skf = sK + NW * NX, *const sPt = skf + NW, *const sp = sPt + NP2,
                *const src = sp + NX, *const sP = img + KPW, *const sAB = sP + NX * NX, *const sQ = sAB + NX * NV,
                *const sq = sQ + NV * NV, *const sT = sq + NV, *const sPc = sT + NX * NV, *const sdx = sPc + NX,
                *const sdw = sdx + NX, *const srec = sdw + NW;   // srec: the stage record as fetched
@@ -1124,8 +1155,7 @@ __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const doubl
   // records (stage 0; an entry of the record, or its zero slot) plus a constant.  The per-stage fetch
   // is then an unconditional load per entry -- no branch around any load -- and all lanes of the
   // wavefront address the same few cache lines.
-  const double *const zer = rb + C::R_ZERO;
-  constexpr size_t sstr = (size_t)C::RS;                  // stage stride of the records
+  constexpr size_t sstr = SLOTS ? (size_t)GS : (size_t)C::RS;   // stage stride of the records
   constexpr int EPL = (NV * NV + LPI - 1) / LPI;   // stage Hessian entries per lane
   constexpr int TPL = (NX * NV + LPI - 1) / LPI;   // entries of T = P [A|B] (and of [A|B]) per lane
   constexpr int RPL = (C::RS + LPI - 1) / LPI;     // record entries per lane
@@ -1214,11 +1244,20 @@ __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const doubl
     if (k > 0) fetch_stage(k - 1);  // travels while this stage is computed
     WSYNC();
     if (k < N - 1) {
-      double *const kp1 = kpb + (size_t)(k + 1) * kps;
+      if constexpr (SLOTS) {
+        ldouble *const kp1 = slots + (size_t)(k + 1) * GS;
 #pragma unroll
-      for (int u = 0; u < KPL; u++) {
-        const int e = lane + LPI * u;
-        if (e < KPW) kp1[e] = kpv[u];
+        for (int u = 0; u < KPL; u++) {
+          const int e = lane + LPI * u;
+          if (e < KPW) kp1[e] = kpv[u];
+        }
+      } else {
+        gdouble *const kp1 = kpb + (size_t)(k + 1) * kps;
+#pragma unroll
+        for (int u = 0; u < KPL; u++) {
+          const int e = lane + LPI * u;
+          if (e < KPW) kp1[e] = kpv[u];
+        }
       }
     }
     if constexpr (!DD) {
@@ -1373,9 +1412,9 @@ __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const doubl
       if (e < NX * NX + NX) {
         const bool isP = e < NX * NX;
         const int i = isP ? e / NX : e - NX * NX, j = isP ? e - i * NX : 0;
-        const double *const a0 = isP ? sQ + i * NV + j : sq + i;
-        const double *const c0 = isP ? sQ + j * NV + i : sq + i;
-        const double *const cq = isP ? sQ + j * NV + NX : sQ + i * NV + NX;
+        const ldouble *const a0 = isP ? sQ + i * NV + j : sq + i;
+        const ldouble *const c0 = isP ? sQ + j * NV + i : sq + i;
+        const ldouble *const cq = isP ? sQ + j * NV + NX : sQ + i * NV + NX;
         double a = *a0, c = *c0;
 #pragma unroll
         for (int l = 0; l < NW; l++) {
@@ -1414,9 +1453,12 @@ __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const doubl
       fv[u] = kpb[(size_t)k * kps + (e < KPW ? e : 0)];
     }
   };
-  if (N > 1) fetch_fwd(1);
+  if (!SLOTS && N > 1) fetch_fwd(1);
   for (int k = 0; k < N; k++) {
-    if (k > 0) {
+    // image of this stage: stage 0's is still in the work area; later ones come back from the gain record
+    // (copied into the work area), or are read where the backward pass left them (SLOTS)
+    const ldouble *const im = (SLOTS && k > 0) ? slots + (size_t)k * GS : img;
+    if (!SLOTS && k > 0) {
 #pragma unroll
       for (int u = 0; u < KPL; u++) {
         const int e = lane + LPI * u;
@@ -1433,8 +1475,10 @@ __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const doubl
         }
       }
     }
-    if (k > 0 && k < N - 1) fetch_fwd(k + 1);
+    if (!SLOTS && k > 0 && k < N - 1) fetch_fwd(k + 1);
     WSYNC();
+    // (the defect of the stage, read before the step of the stage may overwrite it: SLOTS)
+    const double rcv = im[NW * NX + NW + NP2 + NX + (lane < NX ? lane : 0)];
     // dw = kff + K dx (lanes < NW) and nu+ = p + P dx (the next NX lanes) as ONE instruction stream: both
     // are "offset + row . dx" over the image, only the per-lane addresses differ (LDS instruction count
     // is what bounds this kernel when the whole batch iterates)
@@ -1442,9 +1486,9 @@ __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const doubl
     if (lane < NW + NX) {
       const bool isw = lane < NW;
       const int i = isw ? lane : lane - NW;
-      double s = img[isw ? (NW * NX + lane) : (NW * NX + NW + NP2 + i)];
+      double s = im[isw ? (NW * NX + lane) : (NW * NX + NW + NP2 + i)];
 #pragma unroll
-      for (int j = 0; j < NX; j++) s += img[isw ? (lane * NX + j) : (NW * NX + NW + tri(i, j))] * sdx[j];
+      for (int j = 0; j < NX; j++) s += im[isw ? (lane * NX + j) : (NW * NX + NW + tri(i, j))] * sdx[j];
       if (isw) {
         sdw[lane] = s;
         dzv = s;
@@ -1462,13 +1506,13 @@ __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const doubl
         // holonomic chain, closed form of rc + [A|B][dx; dw] (same order of the non-zero terms as the dense
         // product): q rows dx_i + h dx_{n+i} + h2 dw_i, v rows dx_i + h dw_{i-n}
         const bool isq = lane < NQ;
-        double s = src[lane];
+        double s = rcv;
         s += sdx[lane];
         s += (isq ? h : 0.0) * sdx[isq ? NQ + lane : lane];
         s += (isq ? h2 : h) * sdw[NS + (isq ? lane : lane - NQ)];
         dxn = s;
       } else {
-        double s = src[lane];
+        double s = rcv;
 #pragma unroll
         for (int j = 0; j < NX; j++) s += sAB[lane * NV + j] * sdx[j];
 #pragma unroll
@@ -1535,45 +1579,59 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   inst_load(s, W, b);
   bool usec = false;
   const bool recurse = inst_decide<C>(M, s, r, first != 0, usec);
-  if (!recurse) {
-    if (L0) inst_store(s, W, b);
-    return;
-  }
+  if (L0) inst_store(s, W, b);   // (every lane has loaded the words above: same wavefront, program order)
+  if (!recurse) return;
+  const double mu = s.mu;        // nothing else of the instance state stays live across the recursion
   __shared__ double lds[IPB * IPW][RicLds<C, LPI>::LDSW];
-  StepOut so;
-  so.dz = W.dz + b; so.nunew = W.nunew + b; so.SS = (size_t)N * W.Bp; so.KS = (size_t)W.Bp;
-  const bool chol_ok = riccati_recursion<C, LPI>(M, s.mu, usec, lane, lds[wv], W.R + (size_t)b * N * C::RS,
-                                                 W.KP + (size_t)b * N * W.kps, W.kps, so);
-  inst_after_recursion(s, chol_ok, usec);
-  if (L0) inst_store(s, W, b);
+  StepOut<gdouble> so;
+  so.dz = (gdouble *)(W.dz + b); so.nunew = (gdouble *)(W.nunew + b); so.SS = (size_t)N * W.Bp; so.KS = (size_t)W.Bp;
+  const bool chol_ok = riccati_recursion<C, LPI, false, gdouble>(M, mu, usec, lane, (ldouble *)lds[wv],
+                                                                 (const gdouble *)(W.R + (size_t)b * N * C::RS),
+                                                                 (gdouble *)(W.KP + (size_t)b * N * W.kps), W.kps, so);
+  if (L0) {
+    // = inst_after_recursion on the stored words
+    if (!chol_ok) {
+      if (usec) { W.redo[b] = 1; W.force_gn[b] = 1; W.usedc[b] = 0; }
+      else W.status[b] = -5;
+    } else {
+      W.usedc[b] = usec ? 1 : 0;
+      W.newstep[b] = 1;
+      W.amin_p[b] = (unsigned long long)__double_as_longlong(1.0);  // k_step takes the minima next
+      W.amin_d[b] = (unsigned long long)__double_as_longlong(1.0);
+    }
+  }
 }
 
 // ===========================================================================
 // k_step: slack / multiplier steps and step-length partials, stage parallel
 // ===========================================================================
 // What one lane of the step kernel addresses (same convention as SweepIO).
+template <class RP = gdouble>
 struct StepIO {
-  const double *zc, *tc, *lc, *grow, *Jq, *dz, *gfa;
+  const gdouble *zc, *tc, *lc, *grow, *Jq, *gfa;
+  const RP *dz;
   size_t SS;
   unsigned loff;
+  size_t SSd;       // addressing of dz (see SweepIO)
+  unsigned loffd;
 };
 
 // ap, ad: fraction-to-the-boundary step lengths of this stage (1 when no row binds); gphi: its merit slope partial
-template <class C>
-__device__ __forceinline__ void step_body(const DevTables &T, const StepIO &io, const int k, const double mu,
+template <class C, class RP = gdouble>
+__device__ __forceinline__ void step_body(const DevTables &T, const StepIO<RP> &io, const int k, const double mu,
                                           double &ap_out, double &ad_out, double &gphi_out) {
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NV = C::NV;
   const unsigned loff = io.loff;
   const size_t SS = io.SS;
-  const double *__restrict__ zc = io.zc;
-  const double *__restrict__ tc = io.tc;
-  const double *__restrict__ lc = io.lc;
-  const double *__restrict__ grow = io.grow;
-  const double *__restrict__ Jq = io.Jq;
+  const gdouble *__restrict__ zc = io.zc;
+  const gdouble *__restrict__ tc = io.tc;
+  const gdouble *__restrict__ lc = io.lc;
+  const gdouble *__restrict__ grow = io.grow;
+  const gdouble *__restrict__ Jq = io.Jq;
   double dz[NV], z[NV], gfv[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) {
-    dz[j] = io.dz[IDXL(j)];
+    dz[j] = io.dz[(size_t)j * io.SSd + io.loffd];
     z[j] = zc[IDXL(j)];
     gfv[j] = io.gfa[IDXL(j)];
   }
@@ -1642,11 +1700,12 @@ __global__ __launch_bounds__(kSweepBlock) void k_step(const DevModel M, const De
   if (W.status[b] != ST_ACTIVE || !W.newstep[b]) return;
   (void)B;
   const int cur = W.cur[b];
-  StepIO io;
-  io.zc = W.z[cur]; io.tc = W.t[cur]; io.lc = W.lam[cur]; io.grow = W.grow[cur]; io.Jq = W.Jq[cur];
-  io.dz = W.dz; io.gfa = W.gfa;
+  StepIO<gdouble> io;
+  io.zc = (gdouble *)W.z[cur]; io.tc = (gdouble *)W.t[cur]; io.lc = (gdouble *)W.lam[cur]; io.grow = (gdouble *)W.grow[cur];
+  io.Jq = (gdouble *)W.Jq[cur]; io.dz = (gdouble *)W.dz; io.gfa = (gdouble *)W.gfa;
   io.SS = (size_t)M.N * W.Bp;
   io.loff = (unsigned)k * (unsigned)W.Bp + (unsigned)b;
+  io.SSd = io.SS; io.loffd = io.loff;
   double ap, ad, gphi;
   step_body<C>(*Tp, io, k, W.mu[b], ap, ad, gphi);
   // partial minima -> per-instance step lengths (min is order independent: deterministic)
@@ -1655,6 +1714,225 @@ __global__ __launch_bounds__(kSweepBlock) void k_step(const DevModel M, const De
   W.gphi[(size_t)k * W.Bp + b] = gphi;
 }
 
+
+// ===========================================================================
+// k_fused: whole interior-point iterations of an instance inside ONE wavefront
+// ===========================================================================
+// The pass kernels above run the batch in lock step: every pass is four launches, every launch streams the
+// whole iterate through HBM, and the last few stragglers of a batch cost a full launch chain per iteration.
+// Here a wavefront OWNS two instances (32 lanes each, lane = stage) from the first sweep to the converged
+// plan: sweep -> reduction (shuffles) -> decisions (registers) -> Riccati recursion (the instance's 32 lanes,
+// stage blocks in LDS) -> step lengths (shuffles) -> next sweep, with no kernel boundary, no host look and no
+// other wavefront involved.  An instance's state lives in its own contiguous block of the workspace
+// ([instance][slot][32 stages]: a half-wavefront moves 256 contiguous bytes per slot), which only its owner
+// touches, so it is served by the XCD's L2 / the Infinity Cache; stage records go through LDS (point robot)
+// and the per-instance solver words through registers.  Results are bit-identical to the pass kernels: the
+// same sweep_body / step_body / inst_decide / riccati_recursion run, and the reductions use the same trees.
+// Blocks are independent and of one wavefront: the dispatcher backfills a CU as soon as a pair finishes.
+constexpr int kFusedStages = 32;   // stage stride of the per-instance layout = lanes per instance
+
+struct FusedWs {
+  double *p;                      // [B][npar][32]
+  double *z[2], *t[2], *lam[2], *nu[2];
+  double *dz, *nunew, *gfa;
+  double *grow[2], *Jq[2];
+  double *R;                      // [B][N][rs]   (models whose records do not fit LDS)
+  double *KP;                     // [B][N][kps]
+  int *passes;                    // [1] most passes any instance of the last launch needed
+  long long *stamps;              // [blocks][8] cycles per phase (builds with -DRMPC_STAMPS only; development aid)
+  int rs, kps, nv, m, nx, npar, nhs, njqs;
+};
+
+// ordering point for data one lane writes to the workspace and another lane of the same wavefront reads later
+#define GSYNC()                                              \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_s_waitcnt(0);                           \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+
+template <class C, bool REC_LDS, int IPW>
+__global__ __launch_bounds__(32 * IPW, IPW == 1 ? 2 : 1) void k_fused(const DevModel M, const DevTables *__restrict__ Tp, const FusedWs F, const int B,
+                                              const double *__restrict__ xinit, const double *__restrict__ x0,
+                                              const double *__restrict__ params, double *__restrict__ zout,
+                                              int *__restrict__ exitflag, int *__restrict__ iters_out,
+                                              double *__restrict__ kkt, double *__restrict__ obj, const int max_passes) {
+  constexpr int LPI = kFusedStages;
+  constexpr int NX = C::NX, NV = C::NV;
+  const DevTables &T = *Tp;
+  const int half = threadIdx.x / LPI;
+  const int k = threadIdx.x & (LPI - 1);       // stage of this lane; also its lane index inside the instance
+  const int bi = blockIdx.x * IPW + half;   // IPW instances per wavefront (1: the upper 32 lanes are switched off)
+  const bool valid = bi < B;
+  const size_t b = valid ? bi : B - 1;          // clamped: addresses stay legal, nothing is written for !valid
+  const int N = M.N;
+  const bool stage = k < N;
+
+  // LDS of an instance: the work area of the recursion, and (REC_LDS) its 32 stage slots (FusedSlots)
+  constexpr int LW = RicLds<C, LPI>::LDSW;
+  constexpr int GS = FusedSlots<C>::GS;
+  constexpr int DZ_OFF = FusedSlots<C>::DZ_OFF;
+  constexpr int RECW = REC_LDS ? kFusedStages * GS : 0;
+  __shared__ double lds[IPW * (LW + RECW)];
+  ldouble *const work = (ldouble *)lds + half * (LW + RECW);
+  ldouble *const slots = work + LW;
+
+  // ---- per-instance bases of the workspace ----------------------------------------------------------
+  const size_t S = kFusedStages;
+  gdouble *const pz[2] = {(gdouble *)F.z[0] + b * F.nv * S, (gdouble *)F.z[1] + b * F.nv * S};
+  gdouble *const pt[2] = {(gdouble *)F.t[0] + b * F.m * S, (gdouble *)F.t[1] + b * F.m * S};
+  gdouble *const pl[2] = {(gdouble *)F.lam[0] + b * F.m * S, (gdouble *)F.lam[1] + b * F.m * S};
+  gdouble *const pn[2] = {(gdouble *)F.nu[0] + b * F.nx * S, (gdouble *)F.nu[1] + b * F.nx * S};
+  gdouble *const pg[2] = {(gdouble *)F.grow[0] + b * F.nhs * S, (gdouble *)F.grow[1] + b * F.nhs * S};
+  gdouble *const pj[2] = {(gdouble *)F.Jq[0] + b * F.njqs * S, (gdouble *)F.Jq[1] + b * F.njqs * S};
+  gdouble *const pp = (gdouble *)F.p + b * F.npar * S;
+  gdouble *const pdz = (gdouble *)F.dz + b * F.nv * S;
+  gdouble *const pnn = (gdouble *)F.nunew + b * F.nx * S;
+  gdouble *const pgf = (gdouble *)F.gfa + b * F.nv * S;
+  gdouble *const grec = (gdouble *)F.R + b * (size_t)N * C::RS;
+  gdouble *const kpb = (gdouble *)F.KP + b * (size_t)N * F.kps;
+
+  // ---- prologue: ABI rows of this stage -> the instance's block (x_1 := xinit, mpcModel.py:108) -------
+  if (valid && stage) {
+    const double *zr = x0 + (b * N + k) * NV;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      double v = zr[j];
+      if (k == 0 && j < NX) v = xinit[b * NX + j];
+      pz[0][j * S + k] = v;
+    }
+    if constexpr (REC_LDS) {   // the step slots are read (and discarded) by the first sweep: keep them finite
+#pragma unroll
+      for (int j = 0; j < NV + NX; j++) slots[k * GS + DZ_OFF + j] = 0.0;
+    }
+    if (params) {
+      const double *pr = params + (b * N + k) * M.npar;
+      for (int j = 0; j < M.npar; j++) pp[j * S + k] = pr[j];
+    }
+  }
+  Inst s;
+  inst_init(s, M.mu0);
+  if (!valid) s.status = 0;
+  double gphi_sum = 0.0;   // merit slope of the current step (sum over the stages; step phase)
+  GSYNC();
+
+#ifdef RMPC_STAMPS
+  long long st_sweep = 0, st_dec = 0, st_ric = 0, st_step = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
+#define STAMP_A() st_a = __builtin_amdgcn_s_memtime()
+#define STAMP_B(acc) do { st_b = __builtin_amdgcn_s_memtime(); acc += st_b - st_a; st_a = st_b; } while (0)
+#else
+#define STAMP_A()
+#define STAMP_B(acc)
+#endif
+  int pass = 0;
+  for (; pass < max_passes; pass++) {
+    const bool act = (s.status == ST_ACTIVE);
+    if (__ballot(act) == 0ull) break;
+    const bool first = (pass == 0);
+    STAMP_A();
+    // ---- sweep: trial point, model functions, condensing, stage partials -------------------------------
+    Partials q = {0, 0, 0, 0, 0, 0, 0, 0, 1e300, 0};
+    if (act && stage) {
+      const int cur = s.cur, nxt = cur ^ 1;
+      using RP = typename std::conditional<REC_LDS, ldouble, gdouble>::type;
+      SweepIO<RP> io;
+      io.zc = pz[cur]; io.tc = pt[cur]; io.lc = pl[cur]; io.nc = pn[cur];
+      io.zn = pz[nxt]; io.tn = pt[nxt]; io.ln = pl[nxt]; io.nn = pn[nxt];
+      io.pp = pp; io.gro = pg[cur]; io.jqo = pj[cur]; io.grn = pg[nxt]; io.jqn = pj[nxt];
+      io.gfa = pgf;
+      io.SS = S; io.loff = (unsigned)k; io.kstride = 1u;
+      if constexpr (REC_LDS) {
+        io.rec = slots + k * GS;
+        io.dzp = slots + DZ_OFF; io.nup = slots + DZ_OFF + NV;
+        io.SSd = 1; io.loffd = (unsigned)(k * GS); io.kstrided = (unsigned)GS;
+      } else {
+        io.rec = grec + (size_t)k * C::RS;
+        io.dzp = pdz; io.nup = pnn;
+        io.SSd = S; io.loffd = (unsigned)k; io.kstrided = 1u;
+      }
+      constexpr int EM = -1;
+      const bool nostep = first || (s.redo != 0);
+      double alpha = 0.0, adual = 0.0;
+      if (!nostep) {
+        alpha = ldexp(s.amin_p, -s.ls);
+        adual = s.amin_d;
+      }
+      sweep_body<C, EM, RP>(M, T, io, k, first, nostep, alpha, adual, s.mu, q);
+    }
+    Reduced r;
+    r.f = wave_sum<LPI>(q.f); r.th = wave_sum<LPI>(q.th); r.lgs = wave_sum<LPI>(q.logs); r.sumc = wave_sum<LPI>(q.sumc);
+    r.badf = wave_sum<LPI>(q.bad);
+    r.rstat = wave_max<LPI>(q.rstat); r.req = wave_max<LPI>(q.req); r.rineq = wave_max<LPI>(q.rineq);
+    r.rcomp = wave_max<LPI>(q.rcomp); r.minc = wave_min<LPI>(q.minc);
+    r.gphi = first ? 0.0 : gphi_sum;
+    GSYNC();   // trial point and records are complete before any lane reads another lane's part
+    STAMP_B(st_sweep);
+    // ---- decisions, then a new step when the trial was accepted --------------------------------------
+    bool usec = false;
+    bool recurse = false;
+    if (act) recurse = inst_decide<C>(M, s, r, first, usec);
+    STAMP_B(st_dec);
+    if (recurse) {
+      bool ok;
+      if constexpr (REC_LDS) {
+        StepOut<ldouble> so;
+        so.dz = slots + DZ_OFF; so.nunew = slots + DZ_OFF + NV; so.SS = 1; so.KS = GS;
+        ok = riccati_recursion<C, LPI, true, ldouble>(M, s.mu, usec, k, work, slots, nullptr, 0, so, slots);
+      } else {
+        StepOut<gdouble> so;
+        so.dz = pdz; so.nunew = pnn; so.SS = S; so.KS = 1;
+        ok = riccati_recursion<C, LPI, false, gdouble>(M, s.mu, usec, k, work, grec, kpb, F.kps, so);
+      }
+      inst_after_recursion(s, ok, usec);
+    }
+    GSYNC();   // dz, nunew
+    STAMP_B(st_ric);
+    // ---- step lengths of the new step -----------------------------------------------------------------
+    const bool stepping = act && (s.status == ST_ACTIVE) && (s.newstep != 0);
+    double ap = 1.0, ad = 1.0, gp = 0.0;
+    if (stepping && stage) {
+      const int cur = s.cur;
+      using RP = typename std::conditional<REC_LDS, ldouble, gdouble>::type;
+      StepIO<RP> io;
+      io.zc = pz[cur]; io.tc = pt[cur]; io.lc = pl[cur]; io.grow = pg[cur]; io.Jq = pj[cur];
+      io.gfa = pgf;
+      io.SS = S; io.loff = (unsigned)k;
+      if constexpr (REC_LDS) { io.dz = slots + DZ_OFF; io.SSd = 1; io.loffd = (unsigned)(k * GS); }
+      else { io.dz = pdz; io.SSd = S; io.loffd = (unsigned)k; }
+      step_body<C, RP>(T, io, k, s.mu, ap, ad, gp);
+    }
+    ap = wave_min<LPI>(ap); ad = wave_min<LPI>(ad); gp = wave_sum<LPI>(gp);
+    if (stepping) {
+      s.amin_p = fmin(s.amin_p, ap);
+      s.amin_d = fmin(s.amin_d, ad);
+      gphi_sum = gp;
+    }
+    STAMP_B(st_step);
+  }
+#ifdef RMPC_STAMPS
+  if (threadIdx.x == 0) {
+    long long *o = F.stamps + (size_t)blockIdx.x * 8;
+    o[0] = st_sweep; o[1] = st_dec; o[2] = st_ric; o[3] = st_step; o[4] = __builtin_amdgcn_s_memtime() - st_t0; o[5] = pass;
+    o[6] = st_t0;
+  }
+#endif
+  // ---- epilogue: plan in the ABI layout, statistics ------------------------------------------------------
+  GSYNC();
+  if (valid && stage) {
+    const gdouble *zf = pz[s.cur];
+    double *zr = zout + (b * N + k) * NV;
+#pragma unroll
+    for (int j = 0; j < NV; j++) zr[j] = zf[j * S + k];
+  }
+  if (valid && k == 0) {
+    exitflag[b] = (s.status == ST_ACTIVE) ? 0 : s.status;
+    iters_out[b] = s.iters;
+    kkt[b] = fmax(fmax(s.res_stat, s.res_eq), fmax(s.res_ineq, s.res_comp));
+    obj[b] = s.obj;
+  }
+  if (threadIdx.x == 0) atomicMax(F.passes, pass);
+}
 
 // ===========================================================================
 // Scene packing and closed-loop advance: device
@@ -1674,16 +1952,18 @@ struct SceneOff {
 
 // One lane per (instance, stage).  SOA = 0: ABI layout params[b][k][npar] (what
 // MPCPlanner.reset() + set*() + updateDynamicObstacles() produce, mpcPlanner.py:83-210);
-// SOA = 1: straight into the solver's batch-minor parameter array.
+// SOA = 1: straight into the pass kernels' batch-minor parameter array; SOA = 2: into the fused kernel's
+// per-instance layout.
 template <int SOA>
 __global__ __launch_bounds__(256) void k_scene(const SceneDev S, const SceneOff O, double *__restrict__ out, int B, int Bp) {
 #pragma clang fp contract(off)
   const int gid = blockIdx.x * 256 + threadIdx.x;
   int b, k;
-  if (SOA) { b = gid % Bp; k = gid / Bp; } else { k = gid % O.N; b = gid / O.N; }
+  if (SOA == 1) { b = gid % Bp; k = gid / Bp; } else { k = gid % O.N; b = gid / O.N; }
   if (b >= B || k >= O.N) return;
   auto put = [&](int off, double v) __attribute__((always_inline)) {
-    if (SOA) out[((size_t)off * O.N + k) * Bp + b] = v;
+    if (SOA == 1) out[((size_t)off * O.N + k) * Bp + b] = v;
+    else if (SOA == 2) out[((size_t)b * O.npar + off) * kFusedStages + k] = v;   // fused kernel: [instance][slot][32 stages]
     else out[((size_t)b * O.N + k) * O.npar + off] = v;
   };
   // reset(): zeros, then the broadcast weights (mpcPlanner.py:91-104)
@@ -1837,8 +2117,8 @@ static int fail(const std::string &m) {
       return fail(std::string(#x) + ": " + hipGetErrorString(e_));                        \
   } while (0)
 
-enum KernelId { K_PACK = 0, K_SWEEP, K_RICCATI, K_STEP, K_UNPACK };
-static const char *kKernelNames[RMPC_NUM_KERNELS] = {"k_pack", "k_sweep", "k_riccati", "k_step", "k_unpack"};
+enum KernelId { K_PACK = 0, K_SWEEP, K_RICCATI, K_STEP, K_UNPACK, K_FUSED };
+static const char *kKernelNames[RMPC_NUM_KERNELS] = {"k_pack", "k_sweep", "k_riccati", "k_step", "k_unpack", "k_fused"};
 
 struct rmpc_handle {
   rmpc_desc desc;
@@ -1848,6 +2128,10 @@ struct rmpc_handle {
   Ws W;
   Ws Wc;            // compact workspace the last survivors of a batch migrate to (Bpc columns; Bpc == 0: none)
   int Bpc = 0;
+  int fused_ipw = 2;    // instances per wavefront of the fused kernel (development switch RMPC_FUSED_IPW)
+  bool fused = false;   // this model runs the fused kernel (small models, N <= 32); the pass kernels otherwise
+  FusedWs F;
+  int *h_passes = nullptr;  // pinned
   int device = 0;
   int max_batch = 0;
   int Bp = 0;
@@ -2189,6 +2473,9 @@ static void fill_lane_bytes(rmpc_handle *h, int B) {
   h->lane_bytes[K_RICCATI] = 8 * (int64_t)M.N * (ric_rd + ric_wr);
   h->lane_bytes[K_STEP] = 8 * (step_rd + step_wr);
   h->lane_bytes[K_UNPACK] = 16 * (int64_t)B * M.N * M.nv;
+  // fused kernel, per instance: the compulsory I/O of a solve: xinit, x0, parameters in, plan and
+  // four statistics out -- everything in between is the owner wavefront's private state
+  h->lane_bytes[K_FUSED] = 8 * ((int64_t)M.nx + 2 * (int64_t)M.N * M.nv + (int64_t)M.N * M.npar) + 24;
 }
 
 // The workspace the passes currently run in: the batch's own, or the compact one after migration
@@ -2264,6 +2551,61 @@ static void prof_collect(rmpc_handle *h) {
   h->ev_kind.clear();
 }
 
+// ---- fused path ------------------------------------------------------------------------------------------
+static int fused_columns(int max_batch) { return (max_batch + 1) / 2 * 2; }
+static size_t carve_fused(const DevModel &M, int Bcap, void *base, FusedWs &F) {
+  Carver c(base);
+  const size_t S = (size_t)Bcap * kFusedStages;
+  F.nv = M.nv; F.m = M.m; F.nx = M.nx; F.npar = M.npar;
+  F.nhs = M.nh > 0 ? M.nh : 1; F.njqs = M.nfk > 0 ? M.nfk * M.n : 1;
+  F.p = c.take<double>(S * M.npar);
+  for (int i = 0; i < 2; i++) {
+    F.z[i] = c.take<double>(S * M.nv);
+    F.t[i] = c.take<double>(S * M.m);
+    F.lam[i] = c.take<double>(S * M.m);
+    F.nu[i] = c.take<double>(S * M.nx);
+    F.grow[i] = c.take<double>(S * F.nhs);
+    F.Jq[i] = c.take<double>(S * F.njqs);
+  }
+  F.dz = c.take<double>(S * M.nv);
+  F.nunew = c.take<double>(S * M.nx);
+  F.gfa = c.take<double>(S * M.nv);
+  F.rs = rec_layout(M).rs;
+  F.R = c.take<double>((size_t)Bcap * M.N * F.rs);
+  F.kps = (M.nw * M.nx + M.nw + M.nx * (M.nx + 1) / 2 + M.nx + M.nx + 7) / 8 * 8;
+  F.KP = c.take<double>((size_t)Bcap * M.N * F.kps);
+  F.passes = c.take<int>(64);
+  F.stamps = c.take<long long>((size_t)Bcap * 8);
+  return (c.off + 255) & ~(size_t)255;
+}
+static bool fused_supported(int variant, const DevModel &M) {
+  // chain n = 3 and the diff-drive base, horizons that fit the 32 lanes of an instance
+  return (variant == 0 || variant == 1 || variant == 4 || variant == 5) && M.N <= kFusedStages;
+}
+
+template <class C>
+static int launch_fused_t(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
+                          double *d_zout, int *d_exit, int *d_iters, double *d_kkt, double *d_obj, hipStream_t st, int cap) {
+  if (h->F.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
+  if (h->fused_ipw == 1)
+    hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, 1>), dim3(B), dim3(32), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
+                       d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap);
+  else
+    hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, 2>), dim3((B + 1) / 2), dim3(64), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
+                       d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap);
+  return 0;
+}
+static int launch_fused(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
+                        double *d_zout, int *d_exit, int *d_iters, double *d_kkt, double *d_obj, hipStream_t st, int cap) {
+  switch (h->variant) {
+    case 0: return launch_fused_t<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
+    case 1: return launch_fused_t<Cfg<RMPC_ROBOT_CHAIN, 3, 1>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
+    case 4: return launch_fused_t<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
+    case 5: return launch_fused_t<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
+  }
+  return fail("no fused kernel for this model");
+}
+
 static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
                         double *d_zout, int *d_exit, int *d_iters, double *d_kkt, double *d_obj, hipStream_t st,
                         int max_passes_override) {
@@ -2271,6 +2613,23 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
   const DevModel &M = h->M;
   HIPCHK(hipSetDevice(h->device));
   fill_lane_bytes(h, B);
+  if (h->fused) {
+    // one launch: every wavefront carries its two instances from the first sweep to the plan
+    const int cap = max_passes_override > 0 ? max_passes_override : h->max_passes;
+    HIPCHK(hipMemsetAsync(h->F.passes, 0, sizeof(int), st));
+    {
+      ProfScope ps(h, st, K_FUSED);
+      if (launch_fused(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap)) return -1;
+    }
+    HIPCHK(hipGetLastError());
+    h->last_passes = -1;   // on the device (rmpc_last_passes fetches it)
+    if (h->profiling) {
+      HIPCHK(hipStreamSynchronize(st));
+      prof_collect(h);
+      h->prof_bytes[K_FUSED] += (double)B * (double)h->lane_bytes[K_FUSED];
+    }
+    return 0;
+  }
   HIPCHK(hipMemsetAsync(h->W.active_hist, 0, sizeof(int) * (h->max_passes + 8), st));
   {
     ProfScope ps(h, st, K_PACK);
@@ -2368,7 +2727,9 @@ int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch) {
   Ws W;
   const int Bp = (max_batch + 63) / 64 * 64;
   const int Bpc = compact_columns(max_batch);
-  return (int64_t)(carve(M, Bp, passes_cap(M), nullptr, W) + (Bpc ? carve(M, Bpc, 0, nullptr, W) : 0));
+  FusedWs F;
+  const size_t fused = fused_supported(variant_of(*desc), M) ? carve_fused(M, fused_columns(max_batch), nullptr, F) : 0;
+  return (int64_t)(carve(M, Bp, passes_cap(M), nullptr, W) + (Bpc ? carve(M, Bpc, 0, nullptr, W) : 0) + fused);
 }
 
 int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
@@ -2394,7 +2755,11 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   Ws tmp;
   h->Bpc = compact_columns(max_batch);
   const size_t big = carve(h->M, h->Bp, h->max_passes, nullptr, tmp);
-  h->ws_bytes = big + (h->Bpc ? carve(h->M, h->Bpc, 0, nullptr, tmp) : 0);
+  const size_t small = h->Bpc ? carve(h->M, h->Bpc, 0, nullptr, tmp) : 0;
+  h->fused = fused_supported(h->variant, h->M) && !getenv("RMPC_NO_FUSED");   // (debugging switch: pass kernels only)
+  if (const char *e = getenv("RMPC_FUSED_IPW")) h->fused_ipw = (atoi(e) == 1) ? 1 : 2;
+  FusedWs ftmp;
+  h->ws_bytes = big + small + (h->fused ? carve_fused(h->M, fused_columns(max_batch), nullptr, ftmp) : 0);
   e = hipMalloc(&h->ws_base, h->ws_bytes);
   if (e != hipSuccess) { delete h; return fail(std::string("hipMalloc workspace: ") + hipGetErrorString(e)); }
   e = hipMemset(h->ws_base, 0, h->ws_bytes);
@@ -2404,11 +2769,13 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
     carve(h->M, h->Bpc, 0, (char *)h->ws_base + big, h->Wc);
     h->Wc.active_hist = h->W.active_hist;  // one history per batch, whichever workspace the pass ran in
   }
+  if (h->fused) carve_fused(h->M, fused_columns(max_batch), (char *)h->ws_base + big + small, h->F);
   e = hipMalloc((void **)&h->d_T, sizeof(DevTables));
   if (e == hipSuccess) e = hipMemcpy(h->d_T, &h->T, sizeof(DevTables), hipMemcpyHostToDevice);
   if (e != hipSuccess) { (void)hipFree(h->ws_base); delete h; return fail(std::string("row tables: ") + hipGetErrorString(e)); }
   e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_active, sizeof(int), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_passes, sizeof(int), hipHostMallocDefault);
   if (e != hipSuccess) { rmpc_destroy(h); return fail(std::string("stream / pinned word: ") + hipGetErrorString(e)); }
   h->env_no_migrate = getenv("RMPC_NO_MIGRATE") != nullptr;
   h->env_dump_hist = getenv("RMPC_DUMP_HIST") != nullptr;
@@ -2424,6 +2791,7 @@ void rmpc_destroy(rmpc_handle *h) {
   for (void *p : bufs) (void)hipFree(p);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->h_active) (void)hipHostFree(h->h_active);
+  if (h->h_passes) (void)hipHostFree(h->h_passes);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -2513,8 +2881,13 @@ int rmpc_solve_batch_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene
   hipStream_t st = (hipStream_t)stream;   // NULL: the legacy null stream, ordered with the caller's default-stream work
   SceneDev S; SceneOff O;
   scene_args(h, scene, S, O);
-  const int lanes = h->Bp * h->M.N;
-  hipLaunchKernelGGL((k_scene<1>), dim3((lanes + 255) / 256), dim3(256), 0, st, S, O, h->W.p, B, h->Bp);
+  if (h->fused) {
+    const int lanes = B * h->M.N;
+    hipLaunchKernelGGL((k_scene<2>), dim3((lanes + 255) / 256), dim3(256), 0, st, S, O, h->F.p, B, h->Bp);
+  } else {
+    const int lanes = h->Bp * h->M.N;
+    hipLaunchKernelGGL((k_scene<1>), dim3((lanes + 255) / 256), dim3(256), 0, st, S, O, h->W.p, B, h->Bp);
+  }
   return solve_device(h, B, d_xinit, d_x0, nullptr, d_z_out, d_exitflag, d_iters, d_kkt_res, d_obj, st, 0);
 }
 
@@ -2564,13 +2937,33 @@ int rmpc_get_profile(rmpc_handle *h, double *total_ms, int64_t *launches, double
     if (total_alg_bytes) total_alg_bytes[i] = h->prof_bytes[i];
     if (full_launch_bytes)
       full_launch_bytes[i] = (i == K_SWEEP || i == K_STEP) ? L * h->lane_bytes[i]
-                             : (i == K_RICCATI)            ? (int64_t)h->max_batch * h->lane_bytes[i]
-                                                           : h->lane_bytes[i];
+                             : (i == K_RICCATI || i == K_FUSED) ? (int64_t)h->max_batch * h->lane_bytes[i]
+                                                                : h->lane_bytes[i];
   }
   return 0;
 }
 
-int rmpc_last_passes(rmpc_handle *h) { return h ? h->last_passes : -1; }
+int rmpc_last_passes(rmpc_handle *h) {
+  if (!h) return -1;
+  if (h->fused && h->last_passes < 0) {
+    // the fused kernel counts on the device: the most passes any instance of the last launch needed
+    if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(h->h_passes, h->F.passes, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+      return -1;
+    h->last_passes = *h->h_passes;
+  }
+  return h->last_passes;
+}
+
+/* development aid (builds with -DRMPC_STAMPS): per-block phase cycles of the last fused launch, 8 words per block */
+int rmpc_debug_fused_stamps(rmpc_handle *h, long long *out, int nblocks) {
+  if (!h || !h->fused) return fail("no fused workspace");
+  if (nblocks > fused_columns(h->max_batch)) return fail("too many blocks");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, h->F.stamps, sizeof(long long) * 8 * (size_t)nblocks, hipMemcpyDeviceToHost));
+  return 0;
+}
 
 int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x0, const double *params,
                      double *out_Q, double *out_q0, double *out_q1, double *out_rc, double *out_g, double *out_f) {

@@ -136,6 +136,10 @@ struct Cfg {
   static constexpr int RW = R_A5 + (ROBOT_ == RMPC_ROBOT_DIFFDRIVE ? 35 : 0);
   static constexpr int R_ZERO = RW;             // always 0.0: source of the structural zeros of the dense blocks
   static constexpr int RS = (RW + 1 + 7) / 8 * 8;   // record stride (doubles)
+  // fused kernel: the stage records of the owner wavefront's two instances stay in LDS when they are small
+  // (point robot: 2 x 32 x 48 doubles = 24 KB per wavefront; the diff-drive records carry A5 | B5 and would
+  // leave room for two wavefronts per CU only -- they go through the instance's block of the workspace)
+  static constexpr bool FUSED_REC_LDS = (ROBOT_ == RMPC_ROBOT_CHAIN) && (NQ_ <= 3);
 };
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Development aid: phase breakdown of the fused kernel (library built with -DRMPC_STAMPS, RMPC_LIB_PATH set)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from robot_mpcs_amd._lib import Solver  # noqa: E402
+from robot_mpcs_amd.scenarios import DEFAULT_BATCH, make_scenario  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else DEFAULT_BATCH[cfg]
+sc = make_scenario(cfg, B=B, seed=1000)
+s = Solver(sc.desc, max_batch=B)
+s.solve(sc.xinit, sc.x0, sc.params)
+r = s.solve(sc.xinit, sc.x0, sc.params)
+st = s.fused_stamps((B + 1) // 2).astype(float)
+tot = st[:, 4]
+print(f"{cfg} B={B}: blocks {len(st)}, passes mean {st[:, 5].mean():.1f} max {st[:, 5].max():.0f}")
+for i, name in enumerate(["sweep", "decide", "riccati", "step"]):
+    print(f"  {name:8s} {st[:, i].sum() / tot.sum() * 100:5.1f} %   cycles per pass {st[:, i].sum() / st[:, 5].sum():9.0f}")
+print(f"  total cycles per pass {tot.sum() / st[:, 5].sum():.0f}   (memtime ticks at 100 MHz: x10 ns)")
+t0 = st[:, 6] - st[:, 6].min()
+print(f"  block start spread: median {np.median(t0):.0f} max {t0.max():.0f}; kernel span {(t0 + tot).max():.0f} ticks")

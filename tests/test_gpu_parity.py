@@ -452,7 +452,8 @@ def test_device_entry_is_ordered_with_the_callers_stream(rt):
             s.solve_device(256, tx, t0, tp, z, ef, it, kkt, obj)          # stream=None
             zsum = z.sum(dim=(1, 2))                        # consumer op on the same stream, no synchronize
             ef2 = ef + 0
-        assert np.array_equal(ef2.cpu().numpy(), host["exitflag"])
+            ef2_host = ef2.cpu().numpy()                    # (copy on the same stream: the solve call itself does not block)
+        assert np.array_equal(ef2_host, host["exitflag"])
         torch.cuda.synchronize()
         assert np.array_equal(z.cpu().numpy(), host["z"])
         assert torch.equal(zsum, z.sum(dim=(1, 2)))       # the consumer op saw the finished plan, not the NaN fill
