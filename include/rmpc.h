@@ -137,6 +137,15 @@ int rmpc_solve_batch_device(rmpc_handle *h, int B, const double *d_xinit,
                             double *d_z_out, int32_t *d_exitflag, int32_t *d_iters,
                             double *d_kkt_res, double *d_obj, void *stream);
 
+/* Warm start of the multipliers for closed loops (no counterpart in the reference, which warm-starts the plan
+ * only: setX0 / shiftHorizon, mpcPlanner.py:215-236).  mode 1: a solve of B instances that follows a finished solve
+ * of the same B instances on this handle starts instance b from the multipliers of ITS previous solve, shifted by one
+ * stage like the plan (lambda_k <- lambda_{k+1}, nu_k <- nu_{k+1}, last stage repeated), with mu = clamp(1000 *
+ * previous final mu, 1e-6, mu0), slacks t = max(g(x0), 1e-4) and lambda = max(previous, mu / t); an instance whose
+ * previous solve failed starts from zero multipliers and mu0.  mode 0 (default): every solve starts cold.  Changing the mode, or solving another
+ * batch size, forgets the stored multipliers. */
+int rmpc_set_warm_start(rmpc_handle *h, int mode);
+
 /* Workspace size in bytes for a given descriptor / batch (no allocation). */
 int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch);
 
@@ -191,6 +200,11 @@ int rmpc_solve_batch_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene
  * state repeated over the horizon with zero controls (setX0 "current_state", :228-232). */
 int rmpc_advance_device(rmpc_handle *h, int B, const double *d_z_prev, double *d_xinit, double *d_x0,
                         int previous_plan, void *stream);
+/* The same with the exit flags of the solve that produced d_z_prev ([B], device): an instance whose solve failed
+ * (exitflag < 0) restarts from its new state ("current_state" initialisation) whatever previous_plan says -- the
+ * closed-loop fallback of the reference's boxer example (examples/boxer_example.py:194-198). */
+int rmpc_advance_device_flags(rmpc_handle *h, int B, const double *d_z_prev, const int32_t *d_exitflag, double *d_xinit,
+                              double *d_x0, int previous_plan, void *stream);
 
 /* Free-space decomposition on the device: for each of the B*N seed points
  * (e.g. the planned lidar position of instance b at stage k) at most K half-planes

@@ -286,13 +286,27 @@ class StructuredNLP(HorizonNLP):
             rows.append(Jk)
         return np.vstack(rows)
 
+    def var_scale(self):
+        """Column scaling y = D y' handed to scipy: the slack variable carries the weight ws = 1e10 in the cost
+        (ws s^2), which SLSQP's BFGS model cannot digest; with s = s' / sqrt(ws) the term is s'^2.  The NLP
+        itself is unchanged (same optimum in the original variables)."""
+        d = np.ones(self.nw + (self.N - 1) * self.nv)
+        if self.ns:
+            sc = 1.0 / np.sqrt(max(1.0, float(self.P[0, self.d["off_ws"]])))
+            d[0] = sc                                  # stage 1: [s, u]
+            d[self.nw + self.nx:: self.nv] = sc        # stages 2..N: position nx inside [x, s, u]
+        return d
+
     def solve_slsqp(self, Z0, maxiter=400, ftol=1e-13):
         from scipy.optimize import minimize
-        y0 = self.pack(np.asarray(Z0, dtype=float).reshape(self.N, self.nv))
+        D = self.var_scale()
+        y0 = self.pack(np.asarray(Z0, dtype=float).reshape(self.N, self.nv)) / D
+        bnds = [(None if a is None else a / dd, None if b is None else b / dd) for (a, b), dd in zip(self.bounds(), D)]
         res = minimize(
-            self.objective, y0, jac=self.grad, method="SLSQP", bounds=self.bounds(),
-            constraints=[{"type": "eq", "fun": self.eq, "jac": self.eq_jac},
-                         {"type": "ineq", "fun": self.ineq, "jac": self.ineq_jac}],
+            lambda y: self.objective(D * y), y0, jac=lambda y: D * self.grad(D * y), method="SLSQP", bounds=bnds,
+            constraints=[{"type": "eq", "fun": lambda y: self.eq(D * y), "jac": lambda y: self.eq_jac(D * y) * D[None, :]},
+                         {"type": "ineq", "fun": lambda y: self.ineq(D * y), "jac": lambda y: self.ineq_jac(D * y) * D[None, :]}],
             options={"maxiter": maxiter, "ftol": ftol},
         )
+        res.x = D * res.x
         return self.unpack(res.x), res

@@ -83,6 +83,8 @@ def lib():
         L.orc_fk.argtypes = [C.POINTER(OrcDesc), dp, C.c_int, dp, dp]
         L.orc_solve.restype = C.c_int
         L.orc_solve.argtypes = [C.POINTER(OrcDesc), dp, dp, dp, dp, C.POINTER(OrcStats), dp]
+        L.orc_solve_warm.restype = C.c_int
+        L.orc_solve_warm.argtypes = [C.POINTER(OrcDesc), dp, dp, dp, dp, C.POINTER(OrcStats), dp, dp, C.c_double, dp, dp]
         L.orc_solve_batch.restype = C.c_int
         L.orc_solve_batch.argtypes = [C.POINTER(OrcDesc), C.c_int, dp, dp, dp, dp, C.POINTER(OrcStats), C.c_int]
         L.orc_dynamics.restype = C.c_int
@@ -192,6 +194,27 @@ class Oracle:
         if trace:
             out["trace"] = tr[: st.iters + 1]
         return out
+
+    def solve_warm(self, xinit, x0, params, duals=None):
+        """One instance; ``duals`` = (lam [N, m], nu [N, nx], mu) of the previous solve or None (cold start).
+        Returns the usual dict plus ``duals`` for the next call."""
+        xinit = np.ascontiguousarray(xinit, dtype=np.float64)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1)
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1)
+        z = np.zeros(self.N * self.nv)
+        lam_out = np.zeros((self.N, self.m)); nu_out = np.zeros((self.N, self.nx))
+        st = OrcStats()
+        if duals is None:
+            lw = nw = None; mw = 0.0
+        else:
+            lw = _p(np.ascontiguousarray(duals[0], dtype=np.float64)); nw = _p(np.ascontiguousarray(duals[1], dtype=np.float64))
+            mw = float(duals[2])
+        rc = lib().orc_solve_warm(C.byref(self.cd), _p(xinit), _p(x0), _p(params), _p(z), C.byref(st), lw, nw, mw,
+                                  _p(lam_out), _p(nu_out))
+        assert rc == 0, rc
+        return dict(z=z.reshape(self.N, self.nv), exitflag=st.exitflag, iters=st.iters, res_stat=st.res_stat,
+                    res_eq=st.res_eq, res_ineq=st.res_ineq, res_comp=st.res_comp, obj=st.obj, mu=st.mu,
+                    duals=(lam_out, nu_out, st.mu))
 
     def solve_batch(self, xinit, x0, params, nthreads=0):
         xinit = np.ascontiguousarray(xinit, dtype=np.float64)

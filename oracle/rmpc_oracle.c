@@ -764,8 +764,32 @@ static int model_uses_curvature(const orc_desc *d) {
   return 1;
 }
 
+/* Warm start of the multipliers (closed loops; no reference counterpart -- the reference warm-starts the plan
+ * only, mpcPlanner.py:215-236): lam_w [N][m], nu_w [N][nx], mu_w = multipliers and final barrier parameter of the
+ * previous solve of the same instance.  Stage k takes the values of stage k+1 (the last stage is repeated), like
+ * the shifted plan.  Start: mu = clamp(ORC_WARM_KAPPA * mu_w, ORC_WARM_MU_MIN, mu0), t = max(g(z0), ORC_WARM_TMIN),
+ * lam = max(shifted lam, mu / t), nu = shifted nu. */
+#define ORC_WARM_KAPPA 1000.0
+#define ORC_WARM_MU_MIN 1e-6
+#define ORC_WARM_TMIN 1e-4
+static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, const double *params,
+                      double *zout, orc_stats *st, double *trace, const double *lam_w, const double *nu_w,
+                      double mu_w, double *lam_out, double *nu_out);
+
 int orc_solve(const orc_desc *d, const double *xinit, const double *x0, const double *params,
               double *zout, orc_stats *st, double *trace) {
+  return solve_impl(d, xinit, x0, params, zout, st, trace, 0, 0, 0.0, 0, 0);
+}
+
+int orc_solve_warm(const orc_desc *d, const double *xinit, const double *x0, const double *params, double *zout,
+                   orc_stats *st, const double *lam_w, const double *nu_w, double mu_w, double *lam_out,
+                   double *nu_out) {
+  return solve_impl(d, xinit, x0, params, zout, st, 0, lam_w, nu_w, mu_w, lam_out, nu_out);
+}
+
+static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, const double *params,
+                      double *zout, orc_stats *st, double *trace, const double *lam_w, const double *nu_w,
+                      double mu_w, double *lam_out, double *nu_out) {
   int nh, m;
   if (orc_num_rows(d, &nh, &m) != 0) return -1;
   const int N = d->N, nx = d->nx, nv = nvar_of(d), nw = d->ns + d->nu;
@@ -783,13 +807,29 @@ int orc_solve(const orc_desc *d, const double *xinit, const double *x0, const do
   double obj_prev = 0.0;
   int ev = eval_all(d, w, params);
   if (ev != 0) { exitflag = (ev == ORC_EVAL_BAD_AVOID) ? -7 : -10; goto done; }
-  for (int k = 0; k < N; k++)
+  if (lam_w) {
+    mu = ORC_WARM_KAPPA * mu_w;
+    if (mu < ORC_WARM_MU_MIN) mu = ORC_WARM_MU_MIN;
+    if (mu > d->mu0) mu = d->mu0;
+  }
+  for (int k = 0; k < N; k++) {
+    const int ks = k < N - 1 ? k + 1 : k; /* shifted like the plan */
     for (int i = 0; i < m; i++) {
       double gv = w->g[(size_t)k * MRM + i];
-      double tv = gv > ORC_TMIN ? gv : ORC_TMIN;
-      w->t[(size_t)k * m + i] = tv;
-      w->lam[(size_t)k * m + i] = mu / tv;
+      if (lam_w) {
+        double tv = gv > ORC_WARM_TMIN ? gv : ORC_WARM_TMIN;
+        double lc = mu / tv, lw = lam_w[(size_t)ks * m + i];
+        w->t[(size_t)k * m + i] = tv;
+        w->lam[(size_t)k * m + i] = lw > lc ? lw : lc;
+      } else {
+        double tv = gv > ORC_TMIN ? gv : ORC_TMIN;
+        w->t[(size_t)k * m + i] = tv;
+        w->lam[(size_t)k * m + i] = mu / tv;
+      }
     }
+    if (nu_w)
+      for (int i = 0; i < nx; i++) w->nu[(size_t)k * nx + i] = (k == 0) ? 0.0 : nu_w[(size_t)ks * nx + i];
+  }
   for (it = 0;; it++) {
     /* ---- residuals at the current iterate ---- */
     double res_stat = 0, res_eq = 0, res_ineq = 0, res_comp = 0, obj = 0, theta = 0, logsum = 0;
@@ -966,7 +1006,10 @@ int orc_solve(const orc_desc *d, const double *xinit, const double *x0, const do
 done:
   st->exitflag = exitflag;
   st->iters = it;
+  st->mu = mu;
   memcpy(zout, w->z, sizeof(double) * N * nv);
+  if (lam_out) memcpy(lam_out, w->lam, sizeof(double) * N * m);
+  if (nu_out) memcpy(nu_out, w->nu, sizeof(double) * N * nx);
   work_free(w);
   return 0;
 }

@@ -130,6 +130,12 @@ typedef struct orc_stats {
 int orc_solve(const orc_desc *d, const double *xinit, const double *x0,
               const double *params, double *zout, orc_stats *st, double *trace);
 
+/* The same with a warm start of the multipliers (see rmpc_oracle.c): lam_w [N][m], nu_w [N][nx], mu_w from the
+ * previous solve of this instance (its lam_out / nu_out / st->mu), shifted by one stage inside. */
+int orc_solve_warm(const orc_desc *d, const double *xinit, const double *x0, const double *params, double *zout,
+                   orc_stats *st, const double *lam_w, const double *nu_w, double mu_w, double *lam_out,
+                   double *nu_out);
+
 /* Batch, instance-major arrays; nthreads <= 0 -> OpenMP default. */
 int orc_solve_batch(const orc_desc *d, int B, const double *xinit,
                     const double *x0, const double *params, double *zout,

@@ -70,9 +70,9 @@ class RmpcScene(C.Structure):
 # every symbol include/rmpc.h declares
 EXPORTED_SYMBOLS = [
     "rmpc_version", "rmpc_source_hash", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
-    "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_profiling", "rmpc_get_profile",
+    "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_warm_start", "rmpc_set_profiling", "rmpc_get_profile",
     "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep",
-    "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_advance_device", "rmpc_free_space_device",
+    "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_advance_device", "rmpc_advance_device_flags", "rmpc_free_space_device",
 ]
 
 _lib = None
@@ -130,6 +130,8 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_solve_batch_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9
     L.rmpc_workspace_bytes.restype = C.c_int64
     L.rmpc_workspace_bytes.argtypes = [C.POINTER(RmpcDesc), C.c_int]
+    L.rmpc_set_warm_start.restype = C.c_int
+    L.rmpc_set_warm_start.argtypes = [C.c_void_p, C.c_int]
     L.rmpc_set_profiling.restype = C.c_int
     L.rmpc_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.rmpc_get_profile.restype = C.c_int
@@ -148,6 +150,8 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_solve_batch_scene_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(RmpcScene)] + [C.c_void_p] * 8
     L.rmpc_advance_device.restype = C.c_int
     L.rmpc_advance_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.rmpc_advance_device_flags.restype = C.c_int
+    L.rmpc_advance_device_flags.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.rmpc_free_space_device.restype = C.c_int
     L.rmpc_free_space_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     if L.rmpc_desc_size() != C.sizeof(RmpcDesc):
@@ -331,11 +335,19 @@ class Solver:
                                                    ptr(exitflag), ptr(iters), ptr(kkt), ptr(obj), st)
         self._check(rc, "rmpc_solve_batch_scene_device")
 
-    def advance_device(self, B, z_prev, xinit, x0, previous_plan: bool, stream=None):
+    def advance_device(self, B, z_prev, xinit, x0, previous_plan: bool, stream=None, exitflag=None):
+        """``exitflag`` (device int32 [B], optional): instances whose solve failed restart from their state."""
         st = _stream_arg(stream)
-        rc = self._L.rmpc_advance_device(self._h, int(B), C.c_void_p(z_prev.data_ptr()), C.c_void_p(xinit.data_ptr()),
-                                         C.c_void_p(x0.data_ptr()), 1 if previous_plan else 0, st)
-        self._check(rc, "rmpc_advance_device")
+        ef = C.c_void_p(exitflag.data_ptr()) if exitflag is not None else C.c_void_p(0)
+        rc = self._L.rmpc_advance_device_flags(self._h, int(B), C.c_void_p(z_prev.data_ptr()), ef,
+                                               C.c_void_p(xinit.data_ptr()), C.c_void_p(x0.data_ptr()),
+                                               1 if previous_plan else 0, st)
+        self._check(rc, "rmpc_advance_device_flags")
+
+    def set_warm_start(self, enable: bool):
+        """Closed loops: start every solve from the multipliers of the previous solve of the same batch
+        (``rmpc_set_warm_start``); the plan itself is warm-started through ``x0`` as in the reference."""
+        self._check(self._L.rmpc_set_warm_start(self._h, 1 if enable else 0), "rmpc_set_warm_start")
 
     def set_profiling(self, enable: bool):
         self._check(self._L.rmpc_set_profiling(self._h, 1 if enable else 0), "rmpc_set_profiling")

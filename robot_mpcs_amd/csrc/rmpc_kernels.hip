@@ -44,6 +44,11 @@ namespace rmpc {
 
 // solver constants (DESIGN.md, section "Algorithm")
 constexpr double kTMin = 1e-2;
+// warm start of the multipliers (rmpc_set_warm_start; oracle: ORC_WARM_*): mu = clamp(kappa * previous final mu),
+// slacks pushed to kWarmTMin only, multipliers max(previous, mu / t)
+constexpr double kWarmKappa = 1000.0;
+constexpr double kWarmMuMin = 1e-6;
+constexpr double kWarmTMin = 1e-4;
 constexpr double kTau = 0.995;
 constexpr int kSweepBlock = 64;     // threads per k_sweep / k_step block: one wavefront, so that small batches spread over all CUs
 constexpr int kLsMax = 25;
@@ -94,6 +99,9 @@ struct Ws {
   int *active_hist;               // [max_passes] instances still iterating after each pass
   int *act_idx, *n_act;           // compacted list of the instances still iterating, its length
   int *orig;                      // [Bp] compact workspace only: column -> instance of the caller's batch
+  // multipliers of the last solve (warm start of the next one): [m][N][Bp], [nx][N][Bp], final barrier
+  // parameter [Bp]
+  double *wlam, *wnu, *wmu;
 };
 
 #define IDX(slot, k, b) (((size_t)(slot) * W.N + (size_t)(k)) * W.Bp + (size_t)(b))
@@ -132,7 +140,14 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ in, dou
 }
 
 // stage-0 state := xinit (mpcModel.py:108 xinitidx), per-instance state reset
-__global__ __launch_bounds__(256) void k_init(Ws W, const double *__restrict__ xinit, int B, int nx, double mu0) {
+__device__ __forceinline__ double warm_mu(double wmu, double mu0) {
+  double mu = kWarmKappa * wmu;
+  if (mu < kWarmMuMin) mu = kWarmMuMin;
+  if (mu > mu0) mu = mu0;
+  return mu;
+}
+
+__global__ __launch_bounds__(256) void k_init(Ws W, const double *__restrict__ xinit, int B, int nx, double mu0, int warm) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
   for (int j = 0; j < nx; j++) W.z[0][IDX(j, 0, b)] = xinit[(size_t)b * nx + j];
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(256) void k_init(Ws W, const double *__restrict__ x
   W.amin_d[b] = (unsigned long long)__double_as_longlong(1.0);
   W.redo[b] = 0; W.force_gn[b] = 0; W.gn_sticky[b] = 0; W.curv_fail[b] = 0; W.usedc[b] = 0; W.stall[b] = 0;
   W.ls0[b] = 0; W.lsst[b] = 0;
-  W.mu[b] = mu0;
+  W.mu[b] = warm ? warm_mu(W.wmu[b], mu0) : mu0;
   W.rho[b] = 0.0;
   W.phi0[b] = 0.0;
   W.Dd[b] = 0.0;
@@ -198,6 +213,25 @@ __global__ __launch_bounds__(256) void k_unpack(Ws W, double *__restrict__ zout,
       obj[ob] = W.obj[b];
     }
   }
+}
+
+// Multipliers of the finished solve -> the warm-start arrays of the batch's workspace D (W may be the compact
+// workspace: column b then belongs to instance orig[b]).  One lane per (column, stage).
+__global__ __launch_bounds__(256) void k_save_duals(const Ws W, const Ws D, int B, int m, int nx, const int *__restrict__ orig,
+                                                    double mu0) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int b = gid % W.Bp, k = gid / W.Bp;
+  if (b >= B || k >= W.N) return;
+  const int cur = W.cur[b];
+  const int ob = orig ? orig[b] : b;
+  // a failed solve leaves nothing to start from: zero multipliers and mu0 (the warm start then degenerates to
+  // lambda = mu0 / t, nu = 0)
+  const int st = W.status[b];
+  const double mu = W.mu[b];
+  const bool ok = (st == ST_ACTIVE || st >= 0) && isfinite(mu) && mu > 0.0;
+  for (int i = 0; i < m; i++) D.wlam[((size_t)i * D.N + k) * D.Bp + ob] = ok ? W.lam[cur][IDX(i, k, b)] : 0.0;
+  for (int j = 0; j < nx; j++) D.wnu[((size_t)j * D.N + k) * D.Bp + ob] = ok ? W.nu[cur][IDX(j, k, b)] : 0.0;
+  if (k == 0) D.wmu[ob] = ok ? mu : mu0;
 }
 
 // ===========================================================================
@@ -320,6 +354,10 @@ struct SweepIO {
   // the step (dzp, nup) may live elsewhere (fused kernel: in the LDS slots of the instance): own strides
   size_t SSd;
   unsigned loffd, kstrided;
+  // first pass of a warm-started solve: multipliers / costates of the previous solve (same addressing as lc / nc;
+  // stage k takes the values of stage k + 1, like the shifted plan)
+  const gdouble *wl, *wn;
+  int warm;
 };
 // merit / KKT partial sums of one stage (order = enum Part)
 struct Partials { double f, th, logs, rstat, req, rineq, rcomp, sumc, minc, bad; };
@@ -353,8 +391,13 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
   // ---- trial stage vector, costates, next stage's state ------------------------
   double z[NV], xk1[NX], nuk[NX], nun[NX];
   double zo[NV], dzo[NV];   // current iterate and step of this stage (the row steps are recomputed from them)
+  const unsigned loff1 = loff + (k < N - 1 ? io.kstride : 0u);  // next stage, clamped: loads stay unconditional
+  const bool warm = first && (io.warm != 0);
+  // multipliers the rows start from: the current buffer, or (warm first pass) the previous solve's, one stage on
+  const gdouble *__restrict__ lsrc = warm ? io.wl : lc;
+  const unsigned loffl = warm ? loff1 : loff;
+#define IDXLL(slot) ((size_t)(slot) * SS + loffl)
   {
-    const unsigned loff1 = loff + (k < N - 1 ? io.kstride : 0u);  // next stage, clamped: loads stay unconditional
     const size_t SSd = io.SSd;
     const unsigned loffd = io.loffd, loffd1 = io.loffd + (k < N - 1 ? io.kstrided : 0u);
 #pragma unroll
@@ -377,6 +420,12 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
       double v = 0.0, w = 0.0;
       if (!first && k >= 1) v = nostep ? n0[j] : n0[j] + alpha * (n0n[j] - n0[j]);
       if (!first && k < N - 1) w = nostep ? n1[j] : n1[j] + alpha * (n1n[j] - n1[j]);
+      if (warm) {
+        // costates of the previous solve, shifted: nu_k <- nu_{k+1}, nu_{k+1} <- nu_{k+2} (last stage repeated)
+        const unsigned loff2 = loff1 + (k < N - 2 ? io.kstride : 0u);
+        if (k >= 1) v = io.wn[IDXL1(j)];
+        if (k < N - 1) w = io.wn[(size_t)j * SS + loff2];
+      }
       nuk[j] = v;
       nun[j] = w;
       nn[IDXL(j)] = v;
@@ -431,8 +480,10 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
   auto row_core = [&](int i, double g, double tcv, double lcv, double gold, double gdz) __attribute__((always_inline)) -> RowW {
     double tv, lv;
     if (first) {
-      tv = g > kTMin ? g : kTMin;
+      const double tmin = warm ? kWarmTMin : kTMin;
+      tv = g > tmin ? g : tmin;
       lv = mu * frcp(tv);
+      if (warm) lv = lcv > lv ? lcv : lv;   // (lcv: the previous solve's multiplier of this row, one stage on)
     } else {
       const double dtv = gdz + (gold - tcv);
       const double dlv = (mu - tcv * lcv - lcv * dtv) * frcp(tcv);
@@ -472,7 +523,7 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
       const int ii = i >= 0 ? i : 0;
       const int po = T.v_poff[j][u];
       tcv[u] = tc[IDXL(ii)];
-      lcv[u] = lc[IDXL(ii)];
+      lcv[u] = lsrc[IDXLL(ii)];
       const double pl = pp[IDXL(po >= 0 ? po : 0)];
       lim[u] = po >= 0 ? pl : T.v_val[j][u];
     }
@@ -589,7 +640,7 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
       const int i = T.fk_row[r], kind = T.fk_kind[r], ob = T.fk_obst[r], mi = T.fk_mod[r];
       // requests first, arithmetic after
       const int fi = T.fk_idx[r];
-      const double tcv = tc[IDXL(i)], lcv = lc[IDXL(i)], gold = gro[IDXL(i)];
+      const double tcv = tc[IDXL(i)], lcv = lsrc[IDXLL(i)], gold = gro[IDXL(i)];
       double gdz = 0.0;
       {
         double jo[NQ];
@@ -807,7 +858,7 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
 
 template <class C>
 __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
-                                               const int B, const int first) {
+                                               const int B, const int first, const int warm) {
   const int gid = blockIdx.x * kSweepBlock + threadIdx.x;
   const int li = gid % W.Bp;   // position in the compacted list of iterating instances
   const int k = gid / W.Bp;    // uniform per wavefront (Bp % 64 == 0)
@@ -829,6 +880,8 @@ __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevMo
   io.kstride = (unsigned)W.Bp;
   io.SS = (size_t)N * W.Bp;
   io.SSd = io.SS; io.loffd = io.loff; io.kstrided = io.kstride;
+  io.wl = (gdouble *)W.wlam; io.wn = (gdouble *)W.wnu;
+  io.warm = warm;   // (wave uniform; instances without usable multipliers hold zeros and mu0 in the warm arrays)
   // ---- step lengths of this trial --------------------------------------
   // null pass: the current point is re-evaluated unchanged so that the step can be
   // recomputed with the Gauss-Newton blocks (fallback of a failed curvature step)
@@ -1736,6 +1789,7 @@ struct FusedWs {
   double *z[2], *t[2], *lam[2], *nu[2];
   double *dz, *nunew, *gfa;
   double *grow[2], *Jq[2];
+  double *wlam, *wnu, *wmu;       // [B][m][32], [B][nx][32], [B]: multipliers of the last solve (warm start)
   double *R;                      // [B][N][rs]   (models whose records do not fit LDS)
   double *KP;                     // [B][N][kps]
   int *passes;                    // [1] most passes any instance of the last launch needed
@@ -1757,7 +1811,8 @@ __global__ __launch_bounds__(32 * IPW, IPW == 1 ? 2 : 1) void k_fused(const DevM
                                               const double *__restrict__ xinit, const double *__restrict__ x0,
                                               const double *__restrict__ params, double *__restrict__ zout,
                                               int *__restrict__ exitflag, int *__restrict__ iters_out,
-                                              double *__restrict__ kkt, double *__restrict__ obj, const int max_passes) {
+                                              double *__restrict__ kkt, double *__restrict__ obj, const int max_passes,
+                                              const int warm_mode) {
   constexpr int LPI = kFusedStages;
   constexpr int NX = C::NX, NV = C::NV;
   const DevTables &T = *Tp;
@@ -1812,7 +1867,10 @@ __global__ __launch_bounds__(32 * IPW, IPW == 1 ? 2 : 1) void k_fused(const DevM
     }
   }
   Inst s;
-  inst_init(s, M.mu0);
+  gdouble *const pwl = (gdouble *)F.wlam + b * F.m * S;
+  gdouble *const pwn = (gdouble *)F.wnu + b * F.nx * S;
+  const bool warm = warm_mode != 0;
+  inst_init(s, warm ? warm_mu(F.wmu[b], M.mu0) : M.mu0);
   if (!valid) s.status = 0;
   double gphi_sum = 0.0;   // merit slope of the current step (sum over the stages; step phase)
   GSYNC();
@@ -1851,6 +1909,7 @@ __global__ __launch_bounds__(32 * IPW, IPW == 1 ? 2 : 1) void k_fused(const DevM
         io.dzp = pdz; io.nup = pnn;
         io.SSd = S; io.loffd = (unsigned)k; io.kstrided = 1u;
       }
+      io.wl = pwl; io.wn = pwn; io.warm = warm ? 1 : 0;
       constexpr int EM = -1;
       const bool nostep = first || (s.redo != 0);
       double alpha = 0.0, adual = 0.0;
@@ -1924,12 +1983,19 @@ __global__ __launch_bounds__(32 * IPW, IPW == 1 ? 2 : 1) void k_fused(const DevM
     double *zr = zout + (b * N + k) * NV;
 #pragma unroll
     for (int j = 0; j < NV; j++) zr[j] = zf[j * S + k];
+    // multipliers for a warm start of the next solve of this instance (a failed solve leaves zeros and mu0)
+    const bool okd = (s.status == ST_ACTIVE || s.status >= 0) && isfinite(s.mu) && s.mu > 0.0;
+    const gdouble *lf = pl[s.cur], *nf = pn[s.cur];
+    for (int i = 0; i < F.m; i++) pwl[i * S + k] = okd ? lf[i * S + k] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NX; j++) pwn[j * S + k] = okd ? nf[j * S + k] : 0.0;
   }
   if (valid && k == 0) {
     exitflag[b] = (s.status == ST_ACTIVE) ? 0 : s.status;
     iters_out[b] = s.iters;
     kkt[b] = fmax(fmax(s.res_stat, s.res_eq), fmax(s.res_ineq, s.res_comp));
     obj[b] = s.obj;
+    F.wmu[b] = ((s.status == ST_ACTIVE || s.status >= 0) && isfinite(s.mu) && s.mu > 0.0) ? s.mu : M.mu0;
   }
   if (threadIdx.x == 0) atomicMax(F.passes, pass);
 }
@@ -2013,7 +2079,8 @@ __global__ __launch_bounds__(256) void k_scene(const SceneDev S, const SceneOff 
 // mpcPlanner.py:215-226) or the current state repeated (setX0 "current_state", :228-232).
 template <class C>
 __global__ __launch_bounds__(256) void k_advance(const DevModel M, const double *__restrict__ zprev, double *__restrict__ xinit,
-                                                 double *__restrict__ x0, int B, int previous_plan) {
+                                                 double *__restrict__ x0, int B, int previous_plan_all,
+                                                 const int *__restrict__ exitflag) {
   constexpr int NX = C::NX, NS = C::NS, NV = C::NV;
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
@@ -2031,6 +2098,9 @@ __global__ __launch_bounds__(256) void k_advance(const DevModel M, const double 
   }
 #pragma unroll
   for (int j = 0; j < NX; j++) xinit[(size_t)b * NX + j] = xn[j];
+  // an instance whose last solve failed (exitflag < 0) has no plan worth shifting: it restarts from its state,
+  // as the boxer example of the reference does for its linearisation point (boxer_example.py:194-198)
+  const bool previous_plan = previous_plan_all && !(exitflag && exitflag[b] < 0);
   for (int k = 0; k < N; k++) {
     double *o = x0 + ((size_t)b * N + k) * NV;
     if (previous_plan) {
@@ -2128,6 +2198,9 @@ struct rmpc_handle {
   Ws W;
   Ws Wc;            // compact workspace the last survivors of a batch migrate to (Bpc columns; Bpc == 0: none)
   int Bpc = 0;
+  int warm_mode = 0;        // rmpc_set_warm_start
+  bool have_duals = false;  // the warm-start arrays hold the multipliers of a finished solve of duals_B instances
+  int duals_B = 0;
   int fused_ipw = 2;    // instances per wavefront of the fused kernel (development switch RMPC_FUSED_IPW)
   bool fused = false;   // this model runs the fused kernel (small models, N <= 32); the pass kernels otherwise
   FusedWs F;
@@ -2442,6 +2515,9 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   W.act_idx = c.take<int>(Bp);
   W.n_act = c.take<int>(64);
   W.orig = c.take<int>(Bp);
+  W.wlam = c.take<double>(S * M.m);
+  W.wnu = c.take<double>(S * M.nx);
+  W.wmu = c.take<double>(Bp);
   return (c.off + 255) & ~(size_t)255;
 }
 
@@ -2490,7 +2566,8 @@ static int launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hip
   const int B = ph.B;
   const int lanes = ph.W.Bp * h->M.N;
   if (ph.W.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
-  if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B, first);
+  if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B, first,
+                                           (first && h->warm_mode && h->have_duals) ? 1 : 0);
   else if (which == K_RICCATI) {
     if (C::IPB > 1 && B >= kGroupedMin)
     {
@@ -2570,6 +2647,9 @@ static size_t carve_fused(const DevModel &M, int Bcap, void *base, FusedWs &F) {
   F.dz = c.take<double>(S * M.nv);
   F.nunew = c.take<double>(S * M.nx);
   F.gfa = c.take<double>(S * M.nv);
+  F.wlam = c.take<double>(S * M.m);
+  F.wnu = c.take<double>(S * M.nx);
+  F.wmu = c.take<double>(Bcap);
   F.rs = rec_layout(M).rs;
   F.R = c.take<double>((size_t)Bcap * M.N * F.rs);
   F.kps = (M.nw * M.nx + M.nw + M.nx * (M.nx + 1) / 2 + M.nx + M.nx + 7) / 8 * 8;
@@ -2586,13 +2666,14 @@ static bool fused_supported(int variant, const DevModel &M) {
 template <class C>
 static int launch_fused_t(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
                           double *d_zout, int *d_exit, int *d_iters, double *d_kkt, double *d_obj, hipStream_t st, int cap) {
+  const int warm = (h->warm_mode && h->have_duals) ? 1 : 0;
   if (h->F.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
   if (h->fused_ipw == 1)
     hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, 1>), dim3(B), dim3(32), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
-                       d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap);
+                       d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm);
   else
     hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, 2>), dim3((B + 1) / 2), dim3(64), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
-                       d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap);
+                       d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm);
   return 0;
 }
 static int launch_fused(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
@@ -2613,6 +2694,7 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
   const DevModel &M = h->M;
   HIPCHK(hipSetDevice(h->device));
   fill_lane_bytes(h, B);
+  if (h->have_duals && h->duals_B != B) h->have_duals = false;   // multipliers of another batch: cold start
   if (h->fused) {
     // one launch: every wavefront carries its two instances from the first sweep to the plan
     const int cap = max_passes_override > 0 ? max_passes_override : h->max_passes;
@@ -2622,6 +2704,7 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
       if (launch_fused(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap)) return -1;
     }
     HIPCHK(hipGetLastError());
+    h->have_duals = true; h->duals_B = B;   // (the kernel has left the multipliers in the warm-start arrays)
     h->last_passes = -1;   // on the device (rmpc_last_passes fetches it)
     if (h->profiling) {
       HIPCHK(hipStreamSynchronize(st));
@@ -2638,7 +2721,8 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
       hipLaunchKernelGGL(k_pack, g1, dim3(256), 0, st, d_params, h->W.p, B, M.N * M.npar, M.npar, M.N, h->Bp);
     dim3 g2((B + 63) / 64, (M.N * M.nv + 63) / 64);
     hipLaunchKernelGGL(k_pack, g2, dim3(256), 0, st, d_x0, h->W.z[0], B, M.N * M.nv, M.nv, M.N, h->Bp);
-    hipLaunchKernelGGL(k_init, dim3((B + 255) / 256), dim3(256), 0, st, h->W, d_xinit, B, M.nx, M.mu0);
+    hipLaunchKernelGGL(k_init, dim3((B + 255) / 256), dim3(256), 0, st, h->W, d_xinit, B, M.nx, M.mu0,
+                       (h->warm_mode && h->have_duals) ? 1 : 0);
   }
   const int cap = max_passes_override > 0 ? max_passes_override : h->max_passes;
   int pass = 0, next_check = 8;
@@ -2678,6 +2762,18 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
       hipLaunchKernelGGL(k_unpack, gc, dim3(256), 0, st, h->Wc, d_zout, d_exit, d_iters, d_kkt, d_obj, ph.B, M.nv,
                          (const int *)h->Wc.orig);
     }
+  }
+  if (h->warm_mode) {
+    // multipliers for the next solve (the survivors' from the compact workspace, over the stale ones of the first launch)
+    const int lanes = h->W.Bp * M.N;
+    hipLaunchKernelGGL(k_save_duals, dim3((lanes + 255) / 256), dim3(256), 0, st, h->W, h->W, B, M.m, M.nx, (const int *)nullptr, M.mu0);
+    if (migrated) {
+      const int lc = h->Wc.Bp * M.N;
+      hipLaunchKernelGGL(k_save_duals, dim3((lc + 255) / 256), dim3(256), 0, st, h->Wc, h->W, ph.B, M.m, M.nx, (const int *)h->Wc.orig, M.mu0);
+    }
+    h->have_duals = true; h->duals_B = B;
+  } else {
+    h->have_duals = false;
   }
   HIPCHK(hipGetLastError());
   if (h->profiling) {
@@ -2891,23 +2987,29 @@ int rmpc_solve_batch_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene
   return solve_device(h, B, d_xinit, d_x0, nullptr, d_z_out, d_exitflag, d_iters, d_kkt_res, d_obj, st, 0);
 }
 
-int rmpc_advance_device(rmpc_handle *h, int B, const double *d_z_prev, double *d_xinit, double *d_x0,
-                        int previous_plan, void *stream) {
+int rmpc_advance_device_flags(rmpc_handle *h, int B, const double *d_z_prev, const int32_t *d_exitflag, double *d_xinit,
+                              double *d_x0, int previous_plan, void *stream) {
   if (!h || !d_z_prev || !d_xinit || !d_x0) return fail("null argument");
   if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;   // NULL: the legacy null stream, ordered with the caller's default-stream work
   const dim3 g((B + 255) / 256), t(256);
+  const int *ef = (const int *)d_exitflag;
   switch (h->variant) {
-    case 0: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
-    case 1: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 3, 1>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
-    case 2: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 7, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
-    case 3: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 7, 1>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
-    case 4: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
-    case 5: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan); break;
+    case 0: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan, ef); break;
+    case 1: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 3, 1>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan, ef); break;
+    case 2: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 7, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan, ef); break;
+    case 3: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 7, 1>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan, ef); break;
+    case 4: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan, ef); break;
+    case 5: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan, ef); break;
   }
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+int rmpc_advance_device(rmpc_handle *h, int B, const double *d_z_prev, double *d_xinit, double *d_x0,
+                        int previous_plan, void *stream) {
+  return rmpc_advance_device_flags(h, B, d_z_prev, nullptr, d_xinit, d_x0, previous_plan, stream);
 }
 
 int rmpc_free_space_device(int B, int N, int P, int K, double max_radius, const double *d_points,
@@ -2917,6 +3019,13 @@ int rmpc_free_space_device(int B, int N, int P, int K, double max_radius, const 
   hipLaunchKernelGGL(k_fsd, dim3((B * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_points, d_seeds, d_planes,
                      B, N, P, K, max_radius);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int rmpc_set_warm_start(rmpc_handle *h, int mode) {
+  if (!h) return fail("null handle");
+  h->warm_mode = mode ? 1 : 0;
+  h->have_duals = false;
   return 0;
 }
 
@@ -2980,8 +3089,15 @@ int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x
   hipLaunchKernelGGL(k_pack, g1, dim3(256), 0, st, h->d_params, h->W.p, B, M.N * M.npar, M.npar, M.N, h->Bp);
   dim3 g2((B + 63) / 64, (M.N * M.nv + 63) / 64);
   hipLaunchKernelGGL(k_pack, g2, dim3(256), 0, st, h->d_x0, h->W.z[0], B, M.N * M.nv, M.nv, M.N, h->Bp);
-  hipLaunchKernelGGL(k_init, dim3((B + 255) / 256), dim3(256), 0, st, h->W, h->d_xinit, B, M.nx, M.mu0);
-  if (launch_variant(h, Phase{h->W, B}, 1, 0, st, K_SWEEP)) return -1;
+  hipLaunchKernelGGL(k_init, dim3((B + 255) / 256), dim3(256), 0, st, h->W, h->d_xinit, B, M.nx, M.mu0, 0);
+  h->have_duals = false;
+  {
+    const int wm = h->warm_mode;
+    h->warm_mode = 0;
+    const int rc = launch_variant(h, Phase{h->W, B}, 1, 0, st, K_SWEEP);
+    h->warm_mode = wm;
+    if (rc) return -1;
+  }
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
   // gather SoA -> instance-major on the host (debug path, not timed)

@@ -84,3 +84,89 @@ def summarize(allstats, instances_per_rank: int):
         "iters_mean": float(a[:, 4].sum() / (instances_per_rank * a.shape[0])),
         "iters_max": int(a[:, 5].max()), "kkt_res_max_converged": float(a[:, 6].max()),
     }
+
+
+# ---------------------------------------------------------------------------------------------------------
+# One GPU's shard of the mixed fleet as a device-resident closed loop (BASELINE configs[4])
+# ---------------------------------------------------------------------------------------------------------
+class MixedFleetShard:
+    """The per-robot-type blocks of one rank (``partition_mixed``), each with its own solver handle and HIP
+    stream; ``tick()`` runs one control step of all of them: parameters expanded from the compact scene on the
+    device (``rmpc_solve_batch_scene_device``, counterpart of the planner setters, mpcPlanner.py:83-210), solve,
+    plant step with the model's ERK2 map and warm start of the next solve (``rmpc_advance_device``; shifted
+    plan = ``shiftHorizon``, mpcPlanner.py:215-226).  Nothing crosses PCIe between control steps."""
+
+    def __init__(self, counts: dict, device, seed: int = 7, previous_plan: bool = True, warm_duals: bool = True,
+                 options: dict | None = None):
+        import torch
+        from robot_mpcs_amd._lib import Solver
+        from robot_mpcs_amd import scenarios as sn
+        self.torch, self.dev = torch, device
+        self.previous_plan = bool(previous_plan)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+        limits = {"cfg2": (sn.POINT_LIMITS, sn.POINT_LIMITS_U), "cfg3": (sn.BOXER_LIMITS, sn.BOXER_LIMITS_U),
+                  "cfg4": (sn.PANDA_LIMITS, sn.PANDA_LIMITS_U)}
+        self.fleets = []
+        dev_index = device.index if device.index is not None else 0
+        for name, B in counts.items():
+            if B <= 0:
+                continue
+            lim, limu = limits[name]
+            sc = sn.make_scenario(name, B=B, seed=seed)
+            d = dict(sc.desc)
+            if options:
+                d["options"] = dict(d["options"], **options)
+            s = Solver(d, max_batch=B, device=dev_index)
+            s.set_warm_start(bool(warm_duals and previous_plan))
+            ten = dict(goal=t(sc.extra["goal"]), r_body=t(np.full(B, sc.extra["r_body"])),
+                       lower_limits=t(np.tile(lim[0], (B, 1))), upper_limits=t(np.tile(lim[1], (B, 1))),
+                       lower_limits_u=t(np.tile(limu[0], (B, 1))), upper_limits_u=t(np.tile(limu[1], (B, 1))))
+            if "obst_dyn" in sc.extra:
+                ten["obst_dyn"] = t(sc.extra["obst_dyn"])
+            else:
+                rad = sc.extra.get("obst_radius", np.full(sc.extra["obst_pos"].shape[:2], 0.1))
+                ten["obst"] = t(np.concatenate([sc.extra["obst_pos"], rad[:, :, None]], axis=2))
+            N, nv = d["N"], s.nvar
+            self.fleets.append(dict(
+                name=name, B=B, s=s, sc=sc, scene=s.make_scene(sc.setup["mpc"]["weights"], **ten),
+                x=t(sc.xinit), x0=t(sc.x0), z=torch.empty((B, N, nv), dtype=torch.float64, device=device),
+                ef=torch.empty(B, dtype=torch.int32, device=device), it=torch.empty(B, dtype=torch.int32, device=device),
+                kkt=torch.empty(B, dtype=torch.float64, device=device), obj=torch.empty(B, dtype=torch.float64, device=device),
+                stream=torch.cuda.Stream(device=device)))
+        torch.cuda.synchronize(device)
+
+    @property
+    def instances(self) -> int:
+        return sum(f["B"] for f in self.fleets)
+
+    def _one(self, f):
+        st = f["stream"].cuda_stream
+        f["s"].solve_scene_device(f["B"], f["scene"], f["x"], f["x0"], f["z"], f["ef"], f["it"], f["kkt"], f["obj"], stream=st)
+        f["s"].advance_device(f["B"], f["z"], f["x"], f["x0"], previous_plan=self.previous_plan, stream=st,
+                              exitflag=f["ef"])
+
+    def tick(self, sync: bool = True):
+        """One control step of the whole shard.  The fused kernel needs no host look, so the three blocks are
+        simply enqueued on their streams; blocks on the pass kernels (the arm) poll a counter and get a host
+        thread each."""
+        import threading
+        th = [threading.Thread(target=self._one, args=(f,)) for f in self.fleets]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        if sync:
+            self.torch.cuda.synchronize(self.dev)
+
+    def stats(self):
+        """per block: [converged, acceptable, iteration cap, failed, mean iterations] of the last control step"""
+        out = {}
+        for f in self.fleets:
+            ef = f["ef"]
+            out[f["name"]] = [int((ef == 1).sum()), int((ef == 2).sum()), int((ef == 0).sum()), int((ef < 0).sum()),
+                              float(f["it"].float().mean())]
+        return out
+
+    def close(self):
+        for f in self.fleets:
+            f["s"].close()

@@ -22,7 +22,12 @@ CASES = [("cfg2", 8, 101), ("cfg3", 8, 102), ("cfg4", 8, 103)]
 
 def main():
     out = {}
+    only = sys.argv[1:]            # optional: regenerate these cases only, keep the others from the existing file
+    if only and os.path.exists(OUT):
+        out.update(dict(np.load(OUT)))
     for name, B, seed in CASES:
+        if only and name not in only:
+            continue
         sc = make_scenario(name, B=B, seed=seed)
         Z = np.zeros_like(sc.x0); status = np.zeros(B, dtype=np.int32); fun = np.zeros(B); nit = np.zeros(B, dtype=np.int32)
         viol = np.zeros(B)
