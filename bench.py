@@ -1,53 +1,259 @@
 #!/usr/bin/env python3
 """Headline benchmark: batched MPC solves/sec on MI355X.
 
-A *step* is one pass of the hot path -- one ``rmpc_solve_batch_device`` call --
-over one batch of synthetic input that is already resident in HBM when the
-timed region starts.  Workload at N = 1 GPU: BASELINE.json configs[1]
-(pointRobot, horizon 30, batch 4096, random start / goal + 3 static obstacles);
-with ``--gpus N`` every rank solves its own 4096 instances (weak scaling, no
-data-path collective; one RCCL all-reduce for the max-over-ranks time and one
-gather of solve statistics).
+A *step* is one pass of the hot path -- one ``rmpc_solve_batch_device`` call -- over one batch of synthetic
+input that is already resident in HBM when the timed region starts.  Workload at N = 1 GPU: BASELINE.json
+configs[1] (pointRobot, horizon 30, batch 4096, random start / goal + 3 static obstacles); with ``--gpus N``
+every rank solves its own 4096 instances (weak scaling, no data-path collective; one RCCL all-reduce for the
+max-over-ranks time and one all-gather of solve statistics).  Consecutive steps use different input sets
+(``--input-sets``, default 6 x 55 MB per handle rotation) so that the inputs cannot live in the 256 MB
+Infinity Cache.
 
-Throughput mode: ``--streams S`` (default 4) solver handles per GPU, each on its own HIP stream and
-host thread, take the K steps round robin, so the latency-bound iteration tail of one batch (a few
-straggler instances, tiny kernels) overlaps the bandwidth-bound bulk of the next; ``ms_per_step`` is
-elapsed / K, ``batch_latency_ms`` is one batch solved alone.  ``--streams 1`` runs the steps back to back.
+Throughput mode: ``--streams S`` (default 4) solver handles per GPU, each on its own HIP stream, take the K steps
+round robin; ``ms_per_step`` is elapsed / K, ``batch_latency_ms`` is one batch solved alone.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two
-extra objects: ``roofline`` for the dominant kernel (algorithmic bytes per
-launch / average launch duration from HIP events on the solver's stream) and
-``cpu_baseline`` (the CPU oracle port timed on this box's host cores on the
-same inputs; a reported baseline, not the target).
+Prints ONE JSON line on rank 0 (contract in the task description) with
+  ``roofline``      dominant kernel, EXCLUSIVE durations: a one-stream leg outside the timed region with HIP events
+                    around every kernel of the handle's stream (so that kernel time x launches <= the leg's wall
+                    time); algorithmic bytes = SURVEY.md 8(d)'s per-solve figure (compulsory I/O + iterations x
+                    stage workspace) x the solves of one launch; ``traffic`` = HBM bytes per launch from the
+                    committed PMC passes (profiles/);
+  ``legs``          the other robots of the metric on the same box: panda (configs[3]) and boxer (configs[2]);
+  ``cpu_baseline``  the CPU oracle port on this box's host cores, bounded sample, thread-scaling row.
+
+``--config cfg5``: BASELINE configs[4], the mixed fleet as a device-resident closed loop (a step = one control step
+of this rank's per-robot-type blocks, robot_mpcs_amd.fleet.MixedFleetShard).
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP64_VECTOR_TFLOPS = 78.6
 METRIC = "MPC solves/sec (batched) at N=30, pointRobot & panda; 1/2/4/8 MI355X"
+WORKLOADS = {
+    "cfg1": "BASELINE configs[0]: pointRobot N=10, 1 instance",
+    "cfg2": "BASELINE configs[1]: pointRobot N=30, batch=4096 random start/goal + 3 static obstacles",
+    "cfg3": "BASELINE configs[2]: boxer diff-drive N=30, batch=4096, 5 moving obstacles, slack",
+    "cfg4": "BASELINE configs[3]: panda 7-DoF N=20, batch=1024, joint limits + sphere obstacle",
+    "cfg5": "BASELINE configs[4]: mixed fleet, 8192 instances per GPU (4096 pointRobot + 3072 boxer + 1024 panda), "
+            "device-resident closed loop, 100 Hz target",
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--config", default="cfg2", help="cfg2 (headline), cfg3, cfg4, cfg1")
+    ap.add_argument("--config", default="cfg2", help="cfg2 (headline), cfg3, cfg4, cfg1, cfg5 (mixed-fleet loop)")
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: BASELINE batch of the config)")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="solver handles per GPU, each on its own HIP stream and host thread; steps are dealt round "
-                         "robin, so the latency-bound iteration tail of one batch overlaps the bulk of the next")
+    ap.add_argument("--streams", type=int, default=4, help="solver handles per GPU, each on its own HIP stream")
+    ap.add_argument("--input-sets", type=int, default=6, help="distinct resident input sets the steps rotate through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true",
-                    help="do not record per-kernel HIP events inside the timed region")
+    ap.add_argument("--no-legs", action="store_true", help="headline config only (no panda / boxer legs)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the exclusive per-kernel leg")
+    ap.add_argument("--max-iter", type=int, default=25, help="cfg5 only: iteration cap of the real-time loop")
     return ap.parse_args()
+
+
+def survey_bytes_per_solve(d, iters_mean):
+    """compulsory I/O + iterations x stage workspace exchanged once each way, and the Riccati +
+    condensing flops per iteration."""
+    N, nx, nh, npar = d["N"], d["nx"], int(d["nh"]), d["npar"]
+    nv = nx + d["ns"] + d["nu"]
+    nw = nv - nx
+    io = 8 * (nx + 2 * N * nv + N * npar) + 16
+    ws = 16 * N * (nx * nv + 2 * nx + 2 * nv + nv * (nv + 1) // 2 + nh + nh * nv)
+    fl = N * (7.0 / 3.0 * nx ** 3 + 4 * nx ** 2 * nw + 2 * nx * nw ** 2 + nw ** 3 / 3.0) + 2.0 * N * nh * nv ** 2
+    return io, ws, io + iters_mean * ws, fl
+
+
+class Leg:
+    """One config on this rank: S handles / streams, rotating resident inputs."""
+
+    def __init__(self, cfg, B, S, nsets, dev, seed0):
+        import numpy as np
+        import torch
+        from robot_mpcs_amd._lib import Solver
+        from robot_mpcs_amd.scenarios import make_scenario
+        self.torch, self.np, self.dev, self.cfg, self.B, self.S = torch, np, dev, cfg, B, S
+        self.scs = [make_scenario(cfg, B=B, seed=seed0 + 17 * i) for i in range(nsets)]
+        self.d = d = self.scs[0].desc
+        self.N, self.nv = d["N"], d["nx"] + d["ns"] + d["nu"]
+        dev_index = dev.index if dev.index is not None else 0
+        self.solvers = [Solver(d, max_batch=B, device=dev_index) for _ in range(S)]
+        self.inputs = [(torch.from_numpy(sc.xinit).to(dev), torch.from_numpy(sc.x0).to(dev), torch.from_numpy(sc.params).to(dev))
+                       for sc in self.scs]
+        f64, i32 = torch.float64, torch.int32
+        self.outs = [dict(z=torch.empty((B, self.N, self.nv), dtype=f64, device=dev), exit=torch.empty(B, dtype=i32, device=dev),
+                          iters=torch.empty(B, dtype=i32, device=dev), kkt=torch.empty(B, dtype=f64, device=dev),
+                          obj=torch.empty(B, dtype=f64, device=dev)) for _ in range(S)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        self.counter = 0
+        torch.cuda.synchronize(dev)
+
+    def _run(self, i, first, nsteps):
+        o = self.outs[i]
+        for j in range(nsteps):
+            tx, t0, tp = self.inputs[(first + j * self.S) % len(self.inputs)]
+            self.solvers[i].solve_device(self.B, tx, t0, tp, o["z"], o["exit"], o["iters"], o["kkt"], o["obj"],
+                                         stream=self.streams[i].cuda_stream)
+
+    def run(self, total):
+        """total steps dealt round robin to the S handles; one host thread per handle (ctypes releases the GIL; the
+        pass kernels of the arm poll a device counter from their thread)"""
+        S = self.S
+        counts = [total // S + (1 if i < total % S else 0) for i in range(S)]
+        base = self.counter
+        self.counter += total
+        if S == 1:
+            self._run(0, base, counts[0])
+            return
+        th = [threading.Thread(target=self._run, args=(i, base + i, counts[i])) for i in range(S)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    def exclusive(self, nsteps):
+        """one handle, one stream, HIP events around every kernel: exclusive per-kernel durations and the batch latency"""
+        torch = self.torch
+        sv = self.solvers[0]
+        torch.cuda.synchronize(self.dev)
+        t1 = time.perf_counter()
+        self._run(0, self.counter, 1)
+        torch.cuda.synchronize(self.dev)
+        latency_ms = 1e3 * (time.perf_counter() - t1)
+        sv.set_profiling(True)
+        t1 = time.perf_counter()
+        self._run(0, self.counter + 1, nsteps)
+        torch.cuda.synchronize(self.dev)
+        wall_ms = 1e3 * (time.perf_counter() - t1)
+        prof = sv.get_profile()
+        sv.set_profiling(False)
+        self.counter += nsteps + 1
+        return latency_ms, wall_ms, prof
+
+    def stats(self):
+        o = self.outs[0]
+        return o["exit"].cpu().numpy(), o["iters"].cpu().numpy(), o["kkt"].cpu().numpy()
+
+    def close(self):
+        for s in self.solvers:
+            s.close()
+
+
+def timed(leg, steps, warmup, fence):
+    leg.run(max(warmup, leg.S))
+    fence()
+    t0 = time.perf_counter()
+    leg.run(steps)
+    fence()
+    return time.perf_counter() - t0
+
+
+def kernel_report(prof, wall_ms, nsteps, B, d, iters_mean):
+    """per-kernel exclusive figures of the one-stream leg + the roofline object of the dominant kernel"""
+    kern = {k: v for k, v in prof.items() if v["launches"] > 0 and v["total_ms"] > 0}
+    if not kern:
+        return None
+    name = max(kern, key=lambda k: kern[k]["total_ms"])
+    v = kern[name]
+    avg_ms = v["total_ms"] / v["launches"]
+    io, ws, per_solve, fl = survey_bytes_per_solve(d, iters_mean)
+    if name == "k_fused":
+        # one launch = B whole solves: SURVEY 8(d)'s per-solve figure x B
+        alg = B * per_solve
+        note = "k_fused carries B whole solves per launch: algorithmic bytes = B x (IO + iters_mean x WS) of SURVEY.md 8(d)"
+    else:
+        alg = v["total_alg_bytes"] / v["launches"]   # pass kernels: bytes of the lanes still active, averaged (fill_lane_bytes)
+        note = "pass kernel: algorithmic bytes of the lanes still iterating in each launch, averaged over the launches"
+    achieved = alg / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(d.get("_cfg", ""), {}).get(name)
+        except Exception:
+            traffic = None
+    return {
+        "kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+        "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches": int(v["launches"]),
+        "exclusive_leg": {"steps": nsteps, "wall_ms": wall_ms, "kernel_ms_sum": sum(p["total_ms"] for p in kern.values()),
+                          "note": "one handle on one stream, HIP events around every kernel; kernel time <= wall time"},
+        "per_solve": {"compulsory_io_bytes": io, "workspace_bytes_per_iteration": ws, "iters_mean": iters_mean,
+                      "flops_per_iteration": fl},
+        "compulsory_io_GBps": B * io / (avg_ms * 1e-3) / 1e9 if name == "k_fused" else None,
+        "note": note,
+        "all_kernels": {k: {"total_ms": round(p["total_ms"], 3), "launches": int(p["launches"]),
+                            "avg_ms": p["total_ms"] / p["launches"],
+                            "alg_bytes_full_launch": int(p["full_launch_bytes"])} for k, p in kern.items()},
+    }
+
+
+def cpu_baseline(leg, gpu_z, gpu_exit, Solver, make_scenario, local_rank):
+    """the oracle port (OpenMP over instances) on this box's host cores: bounded samples, thread-scaling row"""
+    import numpy as np
+    from oracle.oracle import Oracle
+    from robot_mpcs_amd.fleet import flags_consistent
+    cores = os.cpu_count() or 1
+    sc = leg.scs[(leg.counter - 1) % len(leg.scs)] if False else leg.scs[0]
+    o = Oracle(leg.d)
+    o.solve_batch(sc.xinit[:8], sc.x0[:8], sc.params[:8], nthreads=1)
+    t = time.perf_counter()
+    r1 = o.solve_batch(sc.xinit[:24], sc.x0[:24], sc.params[:24], nthreads=1)
+    per_solve_1t = (time.perf_counter() - t) / 24
+    rows = []
+    best = None
+    for nt in sorted({1, max(1, cores // 2), cores}):
+        nb = int(min(leg.B, max(24, min(4096, 12.0 * nt / per_solve_1t))))     # about 12 s of CPU work per row
+        o.solve_batch(sc.xinit[: min(nb, 4 * nt)], sc.x0[: min(nb, 4 * nt)], sc.params[: min(nb, 4 * nt)], nthreads=nt)
+        t = time.perf_counter()
+        r = o.solve_batch(sc.xinit[:nb], sc.x0[:nb], sc.params[:nb], nthreads=nt)
+        el = time.perf_counter() - t
+        rows.append({"threads": nt, "instances": nb, "seconds": el, "solves_per_s": nb / el})
+        if best is None or nb / el > best[1] / best[2]:
+            best = (nt, nb, el, r)
+    nt, nb, el, r = best
+    # element-wise check against the GPU plan of the same inputs (input set 0, solved again here)
+    s = Solver(leg.d, max_batch=nb, device=local_rank)
+    g = s.solve(sc.xinit[:nb], sc.x0[:nb], sc.params[:nb])
+    s.close()
+    conv = np.isin(r["exitflag"], (1, 2))
+    dmax = float(np.abs(g["z"][conv] - r["z"][conv]).max()) if conv.any() else 0.0
+    sc1 = make_scenario("cfg1", B=1, seed=0)
+    o1 = Oracle(sc1.desc)
+    o1.solve_batch(sc1.xinit, sc1.x0, sc1.params, nthreads=1)
+    t = time.perf_counter()
+    for _ in range(20):
+        o1.solve_batch(sc1.xinit, sc1.x0, sc1.params, nthreads=1)
+    cpu1_ms = 1e3 * (time.perf_counter() - t) / 20
+    s1 = Solver(sc1.desc, max_batch=1, device=local_rank)
+    s1.solve(sc1.xinit, sc1.x0, sc1.params)
+    t = time.perf_counter()
+    for _ in range(20):
+        s1.solve(sc1.xinit, sc1.x0, sc1.params)
+    gpu1_ms = 1e3 * (time.perf_counter() - t) / 20
+    s1.close()
+    return {
+        "value": nb / el, "unit": "solves/s", "cores": nt, "kind": "port",
+        "sample": f"{nb} instances of the same workload (input set 0), one pass, OpenMP over instances; "
+                  "the reference's own CPU path (FORCES Pro) cannot run here",
+        "seconds": el, "thread_scaling": rows, "single_thread_ms_per_solve": 1e3 * per_solve_1t,
+        "exitflags_consistent_with_gpu": bool(flags_consistent(g["exitflag"], r["exitflag"], g["kkt"], 1e-6)),
+        "max_abs_diff_vs_gpu_plan": dmax,
+        "single_instance_cfg1": {"cpu_port_1_thread_ms": cpu1_ms, "hip_host_entry_ms": gpu1_ms,
+                                 "note": "BASELINE configs[0], one solve per call, host-pointer entry (PCIe included)"},
+    }
 
 
 def main():
@@ -74,214 +280,152 @@ def main():
         ge.build()
     if world > 1:
         dist.barrier()
-    from robot_mpcs_amd import fleet
+    from robot_mpcs_amd import _lib, fleet
     from robot_mpcs_amd._lib import Solver
     from robot_mpcs_amd.scenarios import DEFAULT_BATCH, make_scenario
-
-    cfg = args.config
-    B = args.batch or DEFAULT_BATCH[cfg]
-    sc = make_scenario(cfg, B=B, seed=1000 + rank)  # every rank owns different instances
-    d = sc.desc
-    N, nv = d["N"], d["nx"] + d["ns"] + d["nu"]
-    S = max(1, min(args.streams, args.steps))
-    solvers = [Solver(d, max_batch=B, device=local_rank) for _ in range(S)]
-
-    # inputs resident in HBM before the timed region
-    t_xinit = torch.from_numpy(sc.xinit).to(dev)
-    t_x0 = torch.from_numpy(sc.x0).to(dev)
-    t_params = torch.from_numpy(sc.params).to(dev)
-    outs = []
-    for _ in range(S):
-        outs.append(dict(z=torch.empty((B, N, nv), dtype=torch.float64, device=dev),
-                         exit=torch.empty(B, dtype=torch.int32, device=dev), iters=torch.empty(B, dtype=torch.int32, device=dev),
-                         kkt=torch.empty(B, dtype=torch.float64, device=dev), obj=torch.empty(B, dtype=torch.float64, device=dev)))
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    torch.cuda.synchronize(dev)
-
-    def run_steps(i, nsteps):
-        o = outs[i]
-        for _ in range(nsteps):
-            solvers[i].solve_device(B, t_xinit, t_x0, t_params, o["z"], o["exit"], o["iters"], o["kkt"], o["obj"],
-                                    stream=streams[i].cuda_stream)
-
-    def run_all(total):
-        # one host thread per handle (ctypes releases the GIL; a handle is driven by one thread only)
-        import threading
-        counts = [total // S + (1 if i < total % S else 0) for i in range(S)]
-        if S == 1:
-            run_steps(0, counts[0])
-            return
-        th = [threading.Thread(target=run_steps, args=(i, counts[i])) for i in range(S)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+    dd = dist if world > 1 else None
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    run_all(max(args.warmup, S))
-    fence()
-    # HIP events around every kernel of ONE of the S handles (all of its launches in the timed region):
-    # events on all handles cost ~10 % of the throughput they are meant to measure
-    solvers[0].set_profiling(not args.no_kernel_events)
-    t0 = time.perf_counter()
-    run_all(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = {}
-    for sv in solvers:
-        for kname, v in sv.get_profile().items():
-            acc = prof.setdefault(kname, dict(total_ms=0.0, launches=0, total_alg_bytes=0.0, full_launch_bytes=v["full_launch_bytes"]))
-            acc["total_ms"] += v["total_ms"]; acc["launches"] += v["launches"]; acc["total_alg_bytes"] += v["total_alg_bytes"]
-        sv.set_profiling(False)
-    # latency of ONE batch solved alone (outside the timed region, reported for context)
-    solvers[0].set_profiling(not args.no_kernel_events)
-    t1 = time.perf_counter()
-    run_steps(0, 1)
-    torch.cuda.synchronize(dev)
-    batch_latency_ms = 1e3 * (time.perf_counter() - t1)
-    prof_solo = solvers[0].get_profile()
-    solvers[0].set_profiling(False)
-    passes = solvers[0].last_passes()
-    solver = solvers[0]
-    t_z, t_exit, t_iters, t_kkt = outs[0]["z"], outs[0]["exit"], outs[0]["iters"], outs[0]["kkt"]
+    cfg = args.config
+    base = {"metric": METRIC, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "library_source_hash": _lib.source_hash()}
 
-    dd = dist if world > 1 else None
-    elapsed_max = fleet.max_over_ranks(elapsed, dd, dev)   # RCCL all-reduce(MAX)
+    # ------------------------------------------------------------------ cfg5: mixed-fleet closed loop
+    if cfg == "cfg5":
+        part = fleet.partition_mixed(8192 * world, world)[rank]
+        counts = {k: hi - lo for k, (lo, hi) in part.items()}
+        shard = fleet.MixedFleetShard(counts, dev, seed=7 + rank, previous_plan=True, warm_duals=True,
+                                      options={"max_iter": args.max_iter})
+        for _ in range(max(3, args.warmup)):
+            shard.tick()
+        fence()
+        times = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            t1 = time.perf_counter()
+            shard.tick()
+            times.append(1e3 * (time.perf_counter() - t1))
+        fence()
+        elapsed = fleet.max_over_ranks(time.perf_counter() - t0, dd, dev)
+        # exit-flag statistics: 8 further control steps, outside the timed region (reading them costs a host sync each)
+        acc = {k: np.zeros(5) for k in counts}
+        for _ in range(8):
+            shard.tick()
+            for k, v in shard.stats().items():
+                acc[k] += np.array(v, dtype=float) / 8
+        st = np.array([acc[k] for k in ("cfg2", "cfg3", "cfg4")]).ravel()
+        allst = fleet.gather_stats(st, dd, dev)
+        if rank == 0:
+            times = np.array(times)
+            total = 8192 * world
+            per = {}
+            for i, k in enumerate(("cfg2", "cfg3", "cfg4")):
+                a = allst[:, 5 * i: 5 * i + 5]
+                B = counts[k]
+                per[k] = {"instances_per_gpu": B, "usable_share": float((a[:, 0] + a[:, 1]).sum() / (B * world)),
+                          "iteration_cap_per_step": float(a[:, 2].sum()), "failed_per_step": float(a[:, 3].sum()),
+                          "iters_mean": float(a[:, 4].mean())}
+            out = dict(base, value=total * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps,
+                       config={"workload": WORKLOADS["cfg5"], "instances_per_gpu": 8192, "max_iter": args.max_iter,
+                               "warm_start": "shifted plan + multipliers (rmpc_set_warm_start)",
+                               "parallelism": f"{world} x per-robot-type blocks (fleet.partition_mixed), no data-path collective"},
+                       loop={"rate_hz": float(args.steps / elapsed), "ms_p50": float(np.percentile(times, 50)),
+                             "ms_p90": float(np.percentile(times, 90)), "ms_max": float(times.max()),
+                             "deadline_10ms_hit_rate_rank0": float((times <= 10.0).mean())},
+                       per_fleet=per)
+            print(json.dumps(out))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        shard.close()
+        return
 
-    exitflag = t_exit.cpu().numpy()
-    iters = t_iters.cpu().numpy()
-    # RCCL all-gather of six solve statistics per rank (48 B): the only other collective
-    allstats = fleet.gather_stats(fleet.solve_stats(exitflag, iters, t_kkt.cpu().numpy()), dd, dev)
+    # ------------------------------------------------------------------ headline leg
+    B = args.batch or DEFAULT_BATCH[cfg]
+    S = max(1, min(args.streams, args.steps))
+    leg = Leg(cfg, B, S, max(1, args.input_sets), dev, 1000 + 101 * rank)   # every rank owns different instances
+    elapsed = timed(leg, args.steps, args.warmup, fence)
+    elapsed_max = fleet.max_over_ranks(elapsed, dd, dev)     # RCCL all-reduce(MAX)
+    exitflag, iters, kkt = leg.stats()
+    # RCCL all-gather of the solve statistics per rank (56 B): the only other collective
+    allstats = fleet.gather_stats(fleet.solve_stats(exitflag, iters, kkt), dd, dev)
+    latency_ms, excl_wall_ms, prof = (None, None, None)
+    if not args.no_kernel_events:
+        latency_ms, excl_wall_ms, prof = leg.exclusive(8)
+    passes = leg.solvers[0].last_passes()
+    full_chip = None
+    if not args.no_kernel_events and cfg == "cfg2":
+        # the same kernel with the chip full from ONE launch: a batch of S x B instances on one stream (what the
+        # S overlapped streams of the timed region add up to), exclusive HIP-event duration
+        big = Leg(cfg, B * S, 1, 2, dev, 3000 + 101 * rank)
+        big.run(2)
+        torch.cuda.synchronize(dev)
+        _, bwall, bprof = big.exclusive(4)
+        bef, bit, bk = big.stats()
+        full_chip = (big.B, bwall, bprof, float(bit.mean()))
+        big.close()
+
+    legs = {}
+    if not args.no_legs and cfg == "cfg2":
+        # the other robots of the metric, same box, same run (shorter legs)
+        for other in ("cfg4", "cfg3"):
+            lo = Leg(other, DEFAULT_BATCH[other], S, 4, dev, 2000 + 101 * rank)
+            k = max(16, args.steps // 4)
+            el = fleet.max_over_ranks(timed(lo, k, 4, fence), dd, dev)
+            ef, it, kk = lo.stats()
+            st = fleet.summarize(fleet.gather_stats(fleet.solve_stats(ef, it, kk), dd, dev), lo.B)
+            lat, wall, pr = lo.exclusive(4) if not args.no_kernel_events else (None, None, None)
+            d2 = dict(lo.d, _cfg=other)
+            legs[other] = {"workload": WORKLOADS[other], "value": lo.B * world * k / el, "unit": "solves/s", "steps": k,
+                           "ms_per_step": 1e3 * el / k, "batch_latency_ms": lat, "solve_stats": st,
+                           "roofline": kernel_report(pr, wall, 4, lo.B, d2, st["iters_mean"]) if pr else None}
+            lo.close()
 
     if rank == 0:
-        total_solves = B * world * args.steps
-        value = total_solves / elapsed_max
-        out = {
-            "metric": METRIC,
-            "value": value,
-            "unit": "solves/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed_max / args.steps,
-            "batch_latency_ms": batch_latency_ms,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": {"cfg1": "BASELINE configs[0]: pointRobot N=10, 1 instance",
-                             "cfg2": "BASELINE configs[1]: pointRobot N=30, batch=4096 random start/goal + 3 static obstacles",
-                             "cfg3": "BASELINE configs[2]: boxer diff-drive N=30, batch=4096, 5 moving obstacles, slack",
-                             "cfg4": "BASELINE configs[3]: panda 7-DoF N=20, batch=1024, joint limits + sphere obstacle"}[cfg],
-                "batch_per_gpu": B, "horizon": N, "nvar": nv, "npar": d["npar"], "nh": d["nh"],
-                "warm_start": "current_state (cold multipliers, every step solves from scratch)",
-                "tolerances": {k: d["options"][k] for k in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp", "max_iter")},
-                "parallelism": f"{world} x independent shards, no data-path collective",
-                "streams_per_gpu": S,
-            },
-            "solve_stats": dict(fleet.summarize(allstats, B), passes_last_step=passes),
-        }
-        # ---- roofline of the dominant kernel (rank 0's HIP events) -------------------
-        if not args.no_kernel_events:
-            loop = {k: v for k, v in prof.items() if k in ("k_sweep", "k_riccati", "k_step") and v["launches"] > 0}
-            if loop:
-                name = max(loop, key=lambda k: loop[k]["total_ms"])
-                v = loop[name]
-                avg_ms = v["total_ms"] / v["launches"]
-                alg_per_launch = v["total_alg_bytes"] / v["launches"]  # active lanes only, averaged
-                achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9
-                traffic = None
-                tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                if os.path.exists(tfile):
-                    try:
-                        traffic = json.load(open(tfile)).get(cfg, {}).get(name)
-                    except Exception:
-                        traffic = None
-                # whole-solve figures with SURVEY.md 8(d)'s formulas: compulsory I/O + one stage workspace each way
-                # per iteration through HBM, and the Riccati + condensing flop count per iteration
-                nx_, nv_, nh_, np_ = d["nx"], nv, int(d.get("nh", out["config"]["nh"])), d["npar"]
-                nu_w = nv_ - nx_
-                it_avg = float(out["solve_stats"]["iters_mean"])
-                io_b = 8 * (nx_ + 2 * N * nv_ + N * np_) + 16
-                ws_b = 16 * N * (nx_ * nv_ + 2 * nx_ + 2 * nv_ + nv_ * (nv_ + 1) // 2 + nh_ + nh_ * nv_)
-                fl_it = N * (7.0 / 3.0 * nx_ ** 3 + 4 * nx_ ** 2 * nu_w + 2 * nx_ * nu_w ** 2 + nu_w ** 3 / 3.0) + 2.0 * N * nh_ * nv_ ** 2
-                solve_level = {
-                    "bytes_per_solve": io_b + it_avg * ws_b, "achieved_GBps": value * (io_b + it_avg * ws_b) / 1e9,
-                    "frac_hbm": value * (io_b + it_avg * ws_b) / 1e9 / HBM_PEAK_GBPS,
-                    "flops_per_iteration": fl_it, "achieved_fp64_TFLOPs": value * it_avg * fl_it / 1e12,
-                    "frac_fp64_vector": value * it_avg * fl_it / 1e12 / 78.6,
-                    "note": "SURVEY.md 8(d): IO + iters_avg * WS bytes and Riccati + condensing flops per solve, times solves/s",
+        d = dict(leg.d, _cfg=cfg)
+        stats = fleet.summarize(allstats, B)
+        value = B * world * args.steps / elapsed_max
+        out = dict(base, value=value, ms_per_step=1e3 * elapsed_max / args.steps, batch_latency_ms=latency_ms,
+                   config={"workload": WORKLOADS[cfg], "batch_per_gpu": B, "horizon": leg.N, "nvar": leg.nv,
+                           "npar": d["npar"], "nh": d["nh"],
+                           "warm_start": "current_state (cold multipliers, every step solves from scratch)",
+                           "tolerances": {k: d["options"][k] for k in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp", "max_iter")},
+                           "parallelism": f"{world} x independent shards, no data-path collective",
+                           "streams_per_gpu": S, "input_sets": len(leg.scs)},
+                   solve_stats=dict(stats, passes_last_step=passes))
+        if prof:
+            rf = kernel_report(prof, excl_wall_ms, 8, B, d, stats["iters_mean"])
+            if rf:
+                io, ws, per_solve, fl = survey_bytes_per_solve(d, stats["iters_mean"])
+                rf["solve_level"] = {
+                    "bytes_per_solve": per_solve, "achieved_GBps": value * per_solve / 1e9 / world,
+                    "frac_hbm": value * per_solve / 1e9 / world / HBM_PEAK_GBPS,
+                    "achieved_fp64_TFLOPs": value * stats["iters_mean"] * fl / 1e12 / world,
+                    "frac_fp64_vector": value * stats["iters_mean"] * fl / 1e12 / world / FP64_VECTOR_TFLOPS,
+                    "note": "per GPU, throughput mode (all streams): SURVEY.md 8(d) bytes and flops per solve x solves/s",
                 }
-                out["roofline"] = {
-                    "solve_level": solve_level,
-                    "kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg_per_launch,
-                    "algorithmic_bytes_full_launch": int(v["full_launch_bytes"]),
-                    "avg_launch_ms": avg_ms, "launches": int(v["launches"]),
-                    "note": "bytes count only lanes still active in each launch; average over all launches of one of the "
-                            "solver handles in the timed region (HIP events on its stream), in which the kernels of "
-                            "several streams share the GPU (durations include that contention); solo_batch = the same "
-                            "per-kernel figures for one batch solved alone",
-                    "solo_batch": {k: {"avg_ms": p["total_ms"] / p["launches"],
-                                       "alg_GBps": p["total_alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9}
-                                   for k, p in prof_solo.items() if p["launches"] and p["total_ms"] > 0},
-                    "all_kernels": {k: {"total_ms": round(p["total_ms"], 3), "launches": int(p["launches"]),
-                                        "avg_ms": (p["total_ms"] / p["launches"]) if p["launches"] else None,
-                                        "alg_GBps": (p["total_alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9)
-                                        if p["launches"] and p["total_ms"] > 0 else None,
-                                        "alg_bytes_full_launch": int(p["full_launch_bytes"])}
-                                    for k, p in prof.items()},
-                }
-        # ---- CPU baseline: the oracle port on this box's host cores, same inputs ----
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
-            from oracle.oracle import Oracle
-            cores = os.cpu_count() or 1
-            o = Oracle(d)
-            nb = min(B, 4096)
-            o.solve_batch(sc.xinit[:64], sc.x0[:64], sc.params[:64], nthreads=cores)  # warm the threads
-            tc = time.perf_counter()
-            cpu = o.solve_batch(sc.xinit[:nb], sc.x0[:nb], sc.params[:nb], nthreads=cores)
-            tcpu = time.perf_counter() - tc
-            gz = t_z.cpu().numpy()[:nb]
-            same = bool(np.array_equal(cpu["exitflag"], exitflag[:nb]))
-            conv = cpu["exitflag"] == 1
-            dmax = float(np.abs(gz[conv] - cpu["z"][conv]).max()) if conv.any() else 0.0
-            # one instance, one thread, cfg1 -- the closest analogue of the reference's own loop
-            # (one FORCES solve per control step on the CPU) -- and the same single solve through the HIP library
-            sc1 = make_scenario("cfg1", B=1, seed=0)
-            o1 = Oracle(sc1.desc)
-            o1.solve_batch(sc1.xinit, sc1.x0, sc1.params, nthreads=1)
-            t1c = time.perf_counter()
-            for _ in range(20):
-                o1.solve_batch(sc1.xinit, sc1.x0, sc1.params, nthreads=1)
-            cpu1_ms = 1e3 * (time.perf_counter() - t1c) / 20
-            s1 = Solver(sc1.desc, max_batch=1, device=local_rank)
-            s1.solve(sc1.xinit, sc1.x0, sc1.params)
-            t1g = time.perf_counter()
-            for _ in range(20):
-                s1.solve(sc1.xinit, sc1.x0, sc1.params)
-            gpu1_ms = 1e3 * (time.perf_counter() - t1g) / 20
-            s1.close()
-            out["cpu_baseline"] = {
-                "single_instance_cfg1": {"cpu_port_1_thread_ms": cpu1_ms, "hip_host_entry_ms": gpu1_ms,
-                                         "note": "BASELINE configs[0], one solve per call, host-pointer entry (PCIe included)"},
-                "value": nb / tcpu, "unit": "solves/s", "cores": cores, "kind": "port",
-                "sample": f"{nb} instances of the same workload (rank 0's inputs), one pass, OpenMP over instances",
-                "seconds": tcpu, "exitflags_equal_gpu": same, "max_abs_diff_vs_gpu_plan": dmax,
-            }
+                if full_chip:
+                    fb, fwall, fprof, fit = full_chip
+                    fr = kernel_report(fprof, fwall, 4, fb, d, fit)
+                    rf["full_chip_launch"] = {k: fr[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches", "exclusive_leg")}
+                    rf["full_chip_launch"]["instances_per_launch"] = fb
+                    rf["full_chip_launch"]["note"] = ("one launch of %d instances (= %d x the step's batch) alone on the GPU: the kernel with "
+                                                      "every CU busy, as in the timed region where %d launches overlap" % (fb, S, S))
+                out["roofline"] = rf
+        if legs:
+            out["legs"] = legs
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(leg, None, None, Solver, make_scenario, local_rank)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for sv in solvers:
-        sv.close()
+    leg.close()
 
 
 if __name__ == "__main__":

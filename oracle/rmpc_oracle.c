@@ -312,7 +312,14 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
   }
   /* --- inequality modules, YAML order (InequalityManager.py:25-33) --- */
   int row = 0;
-  if (want) { memset(Jg, 0, sizeof(double) * MRM * nv); memset(tl_C, 0, sizeof tl_C); memset(tl_cw, 0, sizeof tl_cw); }
+  if (want) {
+    /* (only the part in use is cleared: the full scratch arrays are 32 KB per stage evaluation) */
+    int nh_used = 0, m_used = 0;
+    orc_num_rows(d, &nh_used, &m_used);
+    memset(Jg, 0, sizeof(double) * (size_t)m_used * nv);
+    for (int r = 0; r < nh_used; r++) memset(tl_C[r], 0, sizeof(double) * n * n);
+    memset(tl_cw, 0, sizeof(double) * nh_used);
+  }
   for (int mi = 0; mi < d->n_modules; mi++) {
     const int kind = d->module_kind[mi];
     const int row0 = row;
@@ -553,8 +560,13 @@ static int eval_all(const orc_desc *d, orc_work *w, const double *params) {
                            w->gf + (size_t)k * nv, w->H + (size_t)k * nv * nv, w->g + (size_t)k * MRM,
                            w->Jg + (size_t)k * MRM * nv, k < N - 1 ? w->xn + (size_t)k * nx : 0,
                            w->A + (size_t)k * nx * nx, w->Bm + (size_t)k * nx * nw, k == 0);
-    memcpy(w->Cc + (size_t)k * ORC_NH_MAX * 64, tl_C, sizeof tl_C);
-    memcpy(w->cw + (size_t)k * ORC_NH_MAX, tl_cw, sizeof tl_cw);
+    {
+      int nh_used = 0;
+      orc_num_rows(d, &nh_used, 0);
+      for (int r = 0; r < nh_used; r++)
+        memcpy(w->Cc + ((size_t)k * ORC_NH_MAX + r) * 64, tl_C[r], sizeof(double) * d->n * d->n);
+      memcpy(w->cw + (size_t)k * ORC_NH_MAX, tl_cw, sizeof(double) * nh_used);
+    }
     if (r == ORC_EVAL_BAD_AVOID) rc = ORC_EVAL_BAD_AVOID;
     else if (r < 0) return r;
   }

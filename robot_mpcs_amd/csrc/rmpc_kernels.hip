@@ -1270,6 +1270,167 @@ __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const doubl
   if (lane < NX) sp[lane] = 0.0;
   bool chol_ok = true;
 
+  // ---- fused kernel, holonomic chain: the backward pass on the instance's LDS slots ---------------------
+  // Same arithmetic per entry as the generic path below, organised for a wavefront that runs alone on its
+  // SIMD: the record is read where the sweep left it (slot k), the image of the stage is written where the
+  // forward pass will read it (slot k: the record is dead by then), every phase issues all its LDS reads
+  // before the first use (one wait per phase instead of one per entry), nothing is predicated except the
+  // stores, and the cost-to-go products of a lane's q entry are formed by the lane itself instead of going
+  // through another LDS exchange: three waits per stage instead of about twenty.
+  constexpr bool FAST = SLOTS && !DD;
+  if constexpr (FAST) {
+    constexpr int OFF_KFF = NW * NX, OFF_PT = NW * NX + NW, OFF_P = OFF_PT + NP2, OFF_RC = OFF_P + NX;
+    // loop-invariant per-lane constants of the Q entries (sum_{a,b} l_a c_b P_ab, see the generic path)
+    int o11[EPL];
+    double l1[EPL], l2[EPL], c1[EPL], c2[EPL];
+    bool qok[EPL];
+#pragma unroll
+    for (int u = 0; u < EPL; u++) {
+      const int e = lane + LPI * u;
+      qok[u] = e < NV * NV;
+      const int ec = qok[u] ? e : 0;
+      const int i = ec / NV, j = ec - i * NV;
+      const int ki = i < NQ ? 0 : (i < NX ? 1 : (i >= NX + NS ? 2 : 3));
+      const int kj = j < NQ ? 0 : (j < NX ? 1 : (j >= NX + NS ? 2 : 3));
+      const bool on = ki != 3 && kj != 3;
+      const int ii = !on ? 0 : (ki == 0 ? i : (ki == 1 ? i - NQ : i - NX - NS));
+      const int jj = !on ? 0 : (kj == 0 ? j : (kj == 1 ? j - NQ : j - NX - NS));
+      o11[u] = ii * NX + jj;
+      l1[u] = !on ? 0.0 : (ki == 0 ? 1.0 : (ki == 1 ? h : h2)); l2[u] = !on ? 0.0 : (ki == 0 ? 0.0 : (ki == 1 ? 1.0 : h));
+      c1[u] = kj == 0 ? 1.0 : (kj == 1 ? h : h2); c2[u] = kj == 0 ? 0.0 : (kj == 1 ? 1.0 : h);
+    }
+    // the lane's gradient entry (lanes < NV)
+    const int lv = lane < NV ? lane : 0;
+    const int kq = lv < NQ ? 0 : (lv < NX ? 1 : (lv >= NX + NS ? 2 : 3));
+    const int iq = kq == 3 ? 0 : (kq == 0 ? lv : (kq == 1 ? lv - NQ : lv - NX - NS));
+    const double l1q = kq == 3 ? 0.0 : (kq == 0 ? 1.0 : (kq == 1 ? h : h2)), l2q = kq == 3 ? 0.0 : (kq == 0 ? 0.0 : (kq == 1 ? 1.0 : h));
+    const int lr = lane < NX ? lane : 0;
+    // gains: lane c <= NX solves for column c of K (c < NX) or for kff (c == NX); sq follows sQ in the work area
+    const int lc = lane <= NX ? lane : 0;
+    // cost-to-go entries of this lane (see the generic path): P(i, j) for e < NX*NX, then p(i)
+    constexpr int PPL2 = (NX * NX + NX + LPI - 1) / LPI;
+    int pa0[PPL2], pc0[PPL2], pqa[PPL2], pqc[PPL2], pka[PPL2], pkc[PPL2], pks[PPL2];
+    bool pisP[PPL2], pok[PPL2];
+#pragma unroll
+    for (int u = 0; u < PPL2; u++) {
+      const int e = lane + LPI * u;
+      pok[u] = e < NX * NX + NX;
+      const int ec = pok[u] ? e : 0;
+      const bool isP = ec < NX * NX;
+      pisP[u] = isP;
+      const int i = isP ? ec / NX : ec - NX * NX, j = isP ? ec - i * NX : 0;
+      // offsets relative to sQ (sq = sQ + NV*NV) and to the slot (K at 0, kff at OFF_KFF)
+      pa0[u] = isP ? i * NV + j : NV * NV + i;
+      pc0[u] = isP ? j * NV + i : NV * NV + i;
+      pqa[u] = i * NV + NX;                          // sQ[i][NX + l]
+      pqc[u] = isP ? j * NV + NX : i * NV + NX;      // cq[l]
+      pka[u] = isP ? j : OFF_KFF;                    // K[l][j] = slot[l*NX + j]  |  kff[l] = slot[OFF_KFF + l]
+      pkc[u] = isP ? i : OFF_KFF;
+      pks[u] = isP ? NX : 1;                         // stride over l
+    }
+    for (int k = N - 1; k >= 0; k--) {
+      ldouble *const slot = slots + (size_t)k * GS;   // record of stage k; becomes its image [K | kff | Pt | p | rc]
+      // ---- phase A: stage Hessian and gradient, with [A|B]^T P [A|B] and [A|B]^T (P rc + p) in closed form ----
+      double r0[EPL], r1[EPL], a11[EPL], a12[EPL], a21[EPL], a22[EPL];
+#pragma unroll
+      for (int u = 0; u < EPL; u++) {
+        r0[u] = slot[qp[u]]; r1[u] = slot[cp[u]];
+        a11[u] = sP[o11[u]]; a12[u] = sP[o11[u] + NQ]; a21[u] = sP[o11[u] + NQ * NX]; a22[u] = sP[o11[u] + NQ * NX + NQ];
+      }
+      double rcl[NX], pr1[NX], pr2[NX];
+#pragma unroll
+      for (int l = 0; l < NX; l++) { rcl[l] = slot[C::R_RC + l]; pr1[l] = sP[iq * NX + l]; pr2[l] = sP[(NQ + iq) * NX + l]; }
+      double pc1 = sp[iq], pc2 = sp[NQ + iq];
+      const double q0v = slot[C::R_Q0 + lv], q1v = slot[C::R_Q1 + lv], rcme = slot[C::R_RC + lr];
+#pragma unroll
+      for (int u = 0; u < EPL; u++) {
+        double v = r0[u] - cwt * r1[u];
+        v += l1[u] * (c1[u] * a11[u] + c2[u] * a12[u]) + l2[u] * (c1[u] * a21[u] + c2[u] * a22[u]);
+        if (qok[u]) sQ[lane + LPI * u] = v;
+      }
+#pragma unroll
+      for (int l = 0; l < NX; l++) { pc1 += pr1[l] * rcl[l]; pc2 += pr2[l] * rcl[l]; }
+      {
+        double v = q0v - mu * q1v;
+        v += l1q * pc1 + l2q * pc2;
+        if (lane < NV) sq[lane] = v;
+      }
+      if (lane < NX) slot[OFF_RC + lane] = rcme;   // (behind the record: [OFF_RC, OFF_RC + NX) is step space, dead now)
+      WSYNC();
+      // ---- phase B: Cholesky of Qww (every lane, registers) and the gains (one column per lane) -------------
+      double qw[NW][NW], colv[NW];
+#pragma unroll
+      for (int j = 0; j < NW; j++)
+#pragma unroll
+        for (int i = j; i < NW; i++) qw[i][j] = sQ[(NX + i) * NV + NX + j];
+#pragma unroll
+      for (int i = 0; i < NW; i++) colv[i] = sQ[lc < NX ? (NX + i) * NV + lc : NV * NV + NX + i];
+      double L[NW][NW], invd[NW];
+#pragma unroll
+      for (int j = 0; j < NW; j++) {
+        double dg = qw[j][j];
+#pragma unroll
+        for (int l = 0; l < j; l++) dg -= L[j][l] * L[j][l];
+        if (!(dg > 0.0)) chol_ok = false;
+        double inv = __builtin_amdgcn_rsq(dg);
+        inv = inv * (1.5 - 0.5 * dg * inv * inv);
+        inv = inv * (1.5 - 0.5 * dg * inv * inv);
+        L[j][j] = dg * inv;
+        invd[j] = inv;
+#pragma unroll
+        for (int i = j + 1; i < NW; i++) {
+          double sacc = qw[i][j];
+#pragma unroll
+          for (int l = 0; l < j; l++) sacc -= L[i][l] * L[j][l];
+          L[i][j] = sacc * inv;
+        }
+      }
+      {
+        double col[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) col[i] = -colv[i];
+        chol_solve<NW>(L, invd, col);
+        if (lane <= NX) {
+#pragma unroll
+          for (int i = 0; i < NW; i++) slot[lane < NX ? i * NX + lane : OFF_KFF + i] = col[i];
+        }
+      }
+      WSYNC();
+      // ---- phase C: cost-to-go P = sym(Qxx + Qxw K), p = qx + Qxw kff ---------------------------------------
+      double pa[PPL2], pcc[PPL2], qa[PPL2][NW], qc[PPL2][NW], ka[PPL2][NW], kc[PPL2][NW];
+#pragma unroll
+      for (int u = 0; u < PPL2; u++) {
+        pa[u] = sQ[pa0[u]]; pcc[u] = sQ[pc0[u]];
+#pragma unroll
+        for (int l = 0; l < NW; l++) {
+          qa[u][l] = sQ[pqa[u] + l]; qc[u][l] = sQ[pqc[u] + l];
+          ka[u][l] = slot[pka[u] + l * pks[u]]; kc[u][l] = slot[pkc[u] + l * pks[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PPL2; u++) {
+        double a = pa[u], c = pcc[u];
+#pragma unroll
+        for (int l = 0; l < NW; l++) {
+          a += qa[u][l] * ka[u][l];
+          c += qc[u][l] * kc[u][l];
+        }
+        const double pn = 0.5 * (a + c);
+        const int e = lane + LPI * u;
+        if (pok[u]) {
+          if (pisP[u]) {
+            sP[e] = pn;
+            const int i = e / NX, j = e - i * NX;
+            if (i <= j) slot[OFF_PT + tri(i, j)] = pn;
+          } else {
+            sp[e - NX * NX] = pn;
+            slot[OFF_P + (e - NX * NX)] = pn;
+          }
+        }
+      }
+      WSYNC();   // (sP / sp of this stage are read by the next stage's phase A)
+    }
+  }
   // prefetched record of the stage about to be processed (lane e holds entry e)
   double recv[RPL];
   auto fetch_stage = [&](int k) __attribute__((always_inline)) {
@@ -1279,8 +1440,8 @@ __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const doubl
       recv[u] = rb[(size_t)k * sstr + (e < C::RS ? e : 0)];
     }
   };
-  fetch_stage(N - 1);
-  for (int k = N - 1; k >= 0; k--) {
+  if constexpr (!FAST) fetch_stage(N - 1);
+  for (int k = FAST ? -1 : N - 1; k >= 0; k--) {
     // -- the image of stage k+1 is complete: it leaves for the gain record (read now, stored after the
     //    barrier); the stage record goes to LDS, the request for the next one leaves ----------------
     double kpv[KPL];
@@ -1510,7 +1671,7 @@ __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const doubl
   for (int k = 0; k < N; k++) {
     // image of this stage: stage 0's is still in the work area; later ones come back from the gain record
     // (copied into the work area), or are read where the backward pass left them (SLOTS)
-    const ldouble *const im = (SLOTS && k > 0) ? slots + (size_t)k * GS : img;
+    const ldouble *const im = (SLOTS && (k > 0 || FAST)) ? slots + (size_t)k * GS : img;
     if (!SLOTS && k > 0) {
 #pragma unroll
       for (int u = 0; u < KPL; u++) {
@@ -2660,6 +2821,7 @@ static size_t carve_fused(const DevModel &M, int Bcap, void *base, FusedWs &F) {
 }
 static bool fused_supported(int variant, const DevModel &M) {
   // chain n = 3 and the diff-drive base, horizons that fit the 32 lanes of an instance
+  if (getenv("RMPC_FUSED_ARM")) return variant >= 0 && variant <= 5 && M.N <= kFusedStages;   // (experiment)
   return (variant == 0 || variant == 1 || variant == 4 || variant == 5) && M.N <= kFusedStages;
 }
 
@@ -2681,6 +2843,8 @@ static int launch_fused(rmpc_handle *h, int B, const double *d_xinit, const doub
   switch (h->variant) {
     case 0: return launch_fused_t<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
     case 1: return launch_fused_t<Cfg<RMPC_ROBOT_CHAIN, 3, 1>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
+    case 2: return launch_fused_t<Cfg<RMPC_ROBOT_CHAIN, 7, 0>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
+    case 3: return launch_fused_t<Cfg<RMPC_ROBOT_CHAIN, 7, 1>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
     case 4: return launch_fused_t<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
     case 5: return launch_fused_t<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
   }
@@ -2859,6 +3023,9 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   e = hipMalloc(&h->ws_base, h->ws_bytes);
   if (e != hipSuccess) { delete h; return fail(std::string("hipMalloc workspace: ") + hipGetErrorString(e)); }
   e = hipMemset(h->ws_base, 0, h->ws_bytes);
+  // (the fill runs on the null stream and may still be in flight when hipMemset returns; solves run on
+  //  non-blocking streams that do not wait for it)
+  if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) { (void)hipFree(h->ws_base); delete h; return fail(std::string("hipMemset workspace: ") + hipGetErrorString(e)); }
   carve(h->M, h->Bp, h->max_passes, h->ws_base, h->W);
   if (h->Bpc) {
