@@ -1655,6 +1655,51 @@ __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const doubl
   }
   if (!chol_ok) return false;
 
+  // ---- fused kernel, holonomic chain without slack: forward rollout with ONE exchange per stage ------------
+  // dw = kff + K dx (lanes < NW), nu+ = p + P dx (the next NX lanes) and dx+ = rc + [A|B][dx; dw] (lanes < NX) are
+  // all formed from dx alone: a lane that needs an entry of dw for its dx+ computes that entry itself (same
+  // expression, same value) instead of waiting for the lane that stores it.  dx ping-pongs between two buffers.
+  constexpr bool FASTF = FAST && (NS == 0);
+  if constexpr (FASTF) {
+    constexpr int OFF_KFF = NW * NX, OFF_PT = NW * NX + NW, OFF_P = OFF_PT + NP2, OFF_RC = OFF_P + NX;
+    // two dx buffers in the work area: sdx (NX) and sT (large, unused by the chain model)
+    ldouble *const dx0 = sdx, *const dx1 = sT;
+    WSYNC();
+    if (lane < NX) dx0[lane] = 0.0;
+    const bool isq = lane < NQ;
+    const int lx = lane < NX ? lane : 0;                    // dx+ entry of this lane
+    const int iw = isq ? lx : lx - NQ;                      // the entry of dw it needs (NS == 0: u_i pairs with q_i and v_i)
+    const bool isn = lane >= NW && lane < NW + NX;          // nu+ entry lane - NW
+    const int in = isn ? lane - NW : 0;
+    int tro[NX];                                            // packed-triangle offsets of row `in` of P
+#pragma unroll
+    for (int j = 0; j < NX; j++) tro[j] = tri(in, j);
+    for (int k = 0; k < N; k++) {
+      const ldouble *const im = slots + (size_t)k * GS;
+      const ldouble *const dxc = (k & 1) ? dx1 : dx0;
+      ldouble *const dxn = (k & 1) ? dx0 : dx1;
+      WSYNC();
+      double dx[NX], kr[NX], pr[NX];
+#pragma unroll
+      for (int j = 0; j < NX; j++) { dx[j] = dxc[j]; kr[j] = im[iw * NX + j]; pr[j] = im[OFF_PT + tro[j]]; }
+      const double kf = im[OFF_KFF + iw], pv = im[OFF_P + in], rcv = im[OFF_RC + lx];
+      const double dxme = dxc[lx], dxv = dxc[isq ? NQ + lx : lx], dxo = dxc[in];
+      double dw = kf, nup = pv;
+#pragma unroll
+      for (int j = 0; j < NX; j++) { dw += kr[j] * dx[j]; nup += pr[j] * dx[j]; }
+      // step of the stage: lanes < NW hold dw (slots NX..), the next NX lanes dx (slots 0..); nu+ for k >= 1
+      if (lane < NW + NX) so.dz[(size_t)(lane < NW ? NX + lane : lane - NW) * so.SS + (size_t)k * so.KS] = lane < NW ? dw : dxo;
+      if (isn && k >= 1) so.nunew[(size_t)in * so.SS + (size_t)k * so.KS] = nup;
+      if (k < N - 1 && lane < NX) {
+        double sx = rcv;
+        sx += dxme;
+        sx += (isq ? h : 0.0) * dxv;
+        sx += (isq ? h2 : h) * dw;
+        dxn[lane] = sx;
+      }
+    }
+    return true;
+  }
   // ---- forward rollout + costates nu+_k = P_k dx_k + p_k ------------------------------------------
   // the image of stage 0 is still in LDS; later stages come back from the gain record (one request each)
   WSYNC();
