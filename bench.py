@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--no-legs", action="store_true", help="headline config only (no panda / boxer legs)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the exclusive per-kernel leg")
     ap.add_argument("--max-iter", type=int, default=25, help="cfg5 only: iteration cap of the real-time loop")
+    ap.add_argument("--episode", type=int, default=40, help="cfg5 only: control steps per episode (then every instance restarts)")
     return ap.parse_args()
 
 
@@ -268,6 +269,19 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
+        # No HIP device: there is no CPU fallback.  Under a multi-rank launch the rendezvous and the rank / argument
+        # plumbing are still exercised (gloo), so that a launch line can be checked on a CPU box; the exit is non-zero.
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo")
+            seen = [None] * world
+            dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "gpus": args.gpus, "steps": args.steps,
+                                          "warmup": args.warmup, "config": args.config})
+            if rank == 0:
+                print(json.dumps({"error": "bench.py needs a HIP device (no CPU fallback)", "world_size": world, "ranks": seen}))
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -306,18 +320,21 @@ def main():
         fence()
         times = []
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
             t1 = time.perf_counter()
+            if i % args.episode == 0:
+                shard.reset()          # new episode: start states, cold plan, cold multipliers
             shard.tick()
             times.append(1e3 * (time.perf_counter() - t1))
         fence()
         elapsed = fleet.max_over_ranks(time.perf_counter() - t0, dd, dev)
-        # exit-flag statistics: 8 further control steps, outside the timed region (reading them costs a host sync each)
+        # exit-flag statistics: one further episode outside the timed region (reading them costs a host sync per step)
         acc = {k: np.zeros(5) for k in counts}
-        for _ in range(8):
+        shard.reset()
+        for _ in range(args.episode):
             shard.tick()
             for k, v in shard.stats().items():
-                acc[k] += np.array(v, dtype=float) / 8
+                acc[k] += np.array(v, dtype=float) / args.episode
         st = np.array([acc[k] for k in ("cfg2", "cfg3", "cfg4")]).ravel()
         allst = fleet.gather_stats(st, dd, dev)
         if rank == 0:
@@ -332,6 +349,7 @@ def main():
                           "iters_mean": float(a[:, 4].mean())}
             out = dict(base, value=total * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps,
                        config={"workload": WORKLOADS["cfg5"], "instances_per_gpu": 8192, "max_iter": args.max_iter,
+                               "episode_steps": args.episode,
                                "warm_start": "shifted plan + multipliers (rmpc_set_warm_start)",
                                "parallelism": f"{world} x per-robot-type blocks (fleet.partition_mixed), no data-path collective"},
                        loop={"rate_hz": float(args.steps / elapsed), "ms_p50": float(np.percentile(times, 50)),

@@ -103,6 +103,7 @@ class MixedFleetShard:
         from robot_mpcs_amd import scenarios as sn
         self.torch, self.dev = torch, device
         self.previous_plan = bool(previous_plan)
+        self.warm_duals = bool(warm_duals and previous_plan)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
         limits = {"cfg2": (sn.POINT_LIMITS, sn.POINT_LIMITS_U), "cfg3": (sn.BOXER_LIMITS, sn.BOXER_LIMITS_U),
                   "cfg4": (sn.PANDA_LIMITS, sn.PANDA_LIMITS_U)}
@@ -129,7 +130,8 @@ class MixedFleetShard:
             N, nv = d["N"], s.nvar
             self.fleets.append(dict(
                 name=name, B=B, s=s, sc=sc, scene=s.make_scene(sc.setup["mpc"]["weights"], **ten),
-                x=t(sc.xinit), x0=t(sc.x0), z=torch.empty((B, N, nv), dtype=torch.float64, device=device),
+                x=t(sc.xinit), x0=t(sc.x0), x_start=t(sc.xinit), x0_start=t(sc.x0),
+                z=torch.empty((B, N, nv), dtype=torch.float64, device=device),
                 ef=torch.empty(B, dtype=torch.int32, device=device), it=torch.empty(B, dtype=torch.int32, device=device),
                 kkt=torch.empty(B, dtype=torch.float64, device=device), obj=torch.empty(B, dtype=torch.float64, device=device),
                 stream=torch.cuda.Stream(device=device)))
@@ -157,6 +159,16 @@ class MixedFleetShard:
             x.join()
         if sync:
             self.torch.cuda.synchronize(self.dev)
+
+    def reset(self):
+        """New episode: every instance back to its start state with a cold plan and cold multipliers (the scenarios
+        have no terminal set and a 1.5 s horizon: in a long run robots that arrive fast at an obstacle or at a limit
+        end up in states from which the NLP is infeasible -- a property of the task, not of the solver; a fleet gets
+        new goals long before)."""
+        for f in self.fleets:
+            with self.torch.cuda.stream(f["stream"]):
+                f["x"].copy_(f["x_start"]); f["x0"].copy_(f["x0_start"])
+            f["s"].set_warm_start(self.warm_duals)   # (re-arming forgets the stored multipliers)
 
     def stats(self):
         """per block: [converged, acceptable, iteration cap, failed, mean iterations] of the last control step"""

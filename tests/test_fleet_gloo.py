@@ -123,3 +123,25 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_launch_line_plumbing_without_a_device(tmp_path):
+    """The driver's multi-GPU launch line (python -m torch.distributed.run ... bench.py --gpus N ...) on a box without a
+    HIP device: rendezvous, RANK / LOCAL_RANK / WORLD_SIZE and the arguments reach every rank, then the program stops
+    with a non-zero exit and says why -- it never falls back to a CPU solver."""
+    import json
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present")
+    port = 33000 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert line, r.stdout + r.stderr
+    d = json.loads(line[-1])
+    assert "HIP device" in d["error"] and d["world_size"] == 2
+    assert sorted(x["rank"] for x in d["ranks"]) == [0, 1] and all(x["gpus"] == 2 and x["steps"] == 3 for x in d["ranks"])
