@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RMPC_VERSION 102 /* 0.1.2: rmpc_source_hash, fused kernel in the profile (RMPC_NUM_KERNELS 6) */
+#define RMPC_VERSION 103 /* 0.1.3: generated model views (rmpc_spec_source, rmpc_spec_name) */
 
 #define RMPC_MAX_JOINTS 8
 #define RMPC_MAX_LINKS 8
@@ -109,7 +109,7 @@ typedef struct rmpc_handle rmpc_handle;
 
 int rmpc_version(void);
 /* sha256 (first 16 hex digits) of the sources this binary was built from (csrc/rmpc_kernels.hip,
- * csrc/rmpc_model.hpp, include/rmpc.h), embedded by __graft_entry__.build(); the Python binding
+ * csrc/rmpc_model.hpp, csrc/rmpc_spec_gen.hpp, include/rmpc.h), embedded by __graft_entry__.build(); the Python binding
  * refuses a library whose hash differs from the sources next to it. */
 const char *rmpc_source_hash(void);
 const char *rmpc_last_error(void);
@@ -224,6 +224,18 @@ int rmpc_free_space_device(int B, int N, int P, int K, double max_radius, const 
 int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x0,
                      const double *params, double *out_Q, double *out_q0,
                      double *out_q1, double *out_rc, double *out_g, double *out_f);
+
+/* Generated solvers.  The reference has FORCES Pro generate C code for ONE problem (mpcModel.py:139-160
+ * generateSolver, examples/makeSolver.py); here the kernels exist in two forms: over runtime row tables (any
+ * descriptor) and over "generated views" -- the same tables as compile-time constants, so that the row loops of
+ * the hot kernels become straight-line code (csrc/rmpc_spec_gen.hpp, one view per shipped configuration).
+ * rmpc_spec_source writes the C++ text of the view of `desc` (struct `name`) into out (cap bytes incl. the
+ * terminating 0) and returns the size it needs, or -1; scripts/gen_specs.py assembles the header from it.
+ * rmpc_create selects a view automatically when every table entry equals the descriptor's; rmpc_spec_name
+ * returns its name ("" = runtime tables). */
+int64_t rmpc_spec_source(const rmpc_desc *desc, const char *name, char *out, int64_t cap);
+const char *rmpc_spec_name(rmpc_handle *h);
+const char *rmpc_spec_for(const rmpc_desc *desc);   /* the view rmpc_create would select (no GPU needed) */
 
 /* Development aid: per-block phase cycle counts of the last fused launch (8 words per block: sweep, decisions,
  * recursion, step, total, passes, start, -); all zero unless the library was built with -DRMPC_STAMPS. */

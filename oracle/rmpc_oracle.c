@@ -524,31 +524,56 @@ typedef struct {
   double *Cc, *cw;
 } orc_work;
 
-static double *dalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
+/* The workspace of a solve is kept per thread and reused while the dimensions stay the same: a fresh set of
+ * callocs per solve costs 1.3 MB of page faults and, with many OpenMP threads, serialises on the process's
+ * address-space lock (the thread-scaling row of bench.py's cpu_baseline).  Every array is zeroed on reuse as calloc
+ * did, except Cc (1 MB), whose entries eval_all writes before the step computation reads them. */
+typedef struct { double **p; size_t n; int zero; } orc_slot;
+static __thread orc_work tl_work;
+static __thread int tl_work_sig[5] = {0, 0, 0, 0, 0};
+static __thread int tl_work_live = 0;
 
-static int work_alloc(orc_work *w, const orc_desc *d, int m) {
-  const int N = d->N, nx = d->nx, nv = nvar_of(d), nw = d->ns + d->nu;
-  w->N = N; w->nx = nx; w->nw = nw; w->nv = nv; w->m = m;
-  w->z = dalloc((size_t)N * nv); w->t = dalloc((size_t)N * m); w->lam = dalloc((size_t)N * m);
-  w->nu = dalloc((size_t)N * nx);
-  w->f = dalloc(N); w->gf = dalloc((size_t)N * nv); w->H = dalloc((size_t)N * nv * nv);
-  w->g = dalloc((size_t)N * MRM); w->Jg = dalloc((size_t)N * MRM * nv);
-  w->xn = dalloc((size_t)N * nx); w->A = dalloc((size_t)N * nx * nx); w->Bm = dalloc((size_t)N * nx * nw);
-  w->Q = dalloc((size_t)N * nv * nv); w->qv = dalloc((size_t)N * nv); w->rc = dalloc((size_t)N * nx);
-  w->K = dalloc((size_t)N * nw * nx); w->kff = dalloc((size_t)N * nw);
-  w->P = dalloc((size_t)N * nx * nx); w->pv = dalloc((size_t)N * nx);
-  w->dz = dalloc((size_t)N * nv); w->dtt = dalloc((size_t)N * m); w->dlam = dalloc((size_t)N * m);
-  w->nunew = dalloc((size_t)N * nx);
-  w->zt = dalloc((size_t)N * nv); w->tt = dalloc((size_t)N * m); w->gt = dalloc((size_t)N * MRM);
-  w->xnt = dalloc((size_t)N * nx);
-  w->Cc = dalloc((size_t)N * ORC_NH_MAX * 64); w->cw = dalloc((size_t)N * ORC_NH_MAX);
-  return 0;
+static int work_slots(orc_work *w, const orc_desc *d, int m, orc_slot *sl) {
+  const size_t N = d->N, nx = d->nx, nv = nvar_of(d), nw = d->ns + d->nu, M = m;
+  int n = 0;
+#define SLOT(f, cnt, z) do { sl[n].p = &w->f; sl[n].n = (cnt); sl[n].zero = (z); n++; } while (0)
+  SLOT(z, N * nv, 1); SLOT(t, N * M, 1); SLOT(lam, N * M, 1); SLOT(nu, N * nx, 1);
+  SLOT(f, N, 1); SLOT(gf, N * nv, 1); SLOT(H, N * nv * nv, 1);
+  SLOT(g, N * MRM, 1); SLOT(Jg, N * MRM * nv, 1);
+  SLOT(xn, N * nx, 1); SLOT(A, N * nx * nx, 1); SLOT(Bm, N * nx * nw, 1);
+  SLOT(Q, N * nv * nv, 1); SLOT(qv, N * nv, 1); SLOT(rc, N * nx, 1);
+  SLOT(K, N * nw * nx, 1); SLOT(kff, N * nw, 1); SLOT(P, N * nx * nx, 1); SLOT(pv, N * nx, 1);
+  SLOT(dz, N * nv, 1); SLOT(dtt, N * M, 1); SLOT(dlam, N * M, 1); SLOT(nunew, N * nx, 1);
+  SLOT(zt, N * nv, 1); SLOT(tt, N * M, 1); SLOT(gt, N * MRM, 1); SLOT(xnt, N * nx, 1);
+  SLOT(Cc, N * ORC_NH_MAX * 64, 0); SLOT(cw, N * ORC_NH_MAX, 1);
+#undef SLOT
+  return n;
 }
+
 static void work_free(orc_work *w) {
   free(w->z); free(w->t); free(w->lam); free(w->nu); free(w->f); free(w->gf); free(w->H);
   free(w->g); free(w->Jg); free(w->xn); free(w->A); free(w->Bm); free(w->Q); free(w->qv);
   free(w->rc); free(w->K); free(w->kff); free(w->P); free(w->pv); free(w->dz); free(w->dtt);
   free(w->dlam); free(w->nunew); free(w->zt); free(w->tt); free(w->gt); free(w->xnt); free(w->Cc); free(w->cw);
+}
+
+/* the calling thread's workspace for these dimensions, zeroed like a fresh calloc (owned by the thread: not freed) */
+static orc_work *work_get(const orc_desc *d, int m) {
+  orc_work *w = &tl_work;
+  orc_slot sl[32];
+  const int sig[5] = {d->N, d->nx, d->ns + d->nu, nvar_of(d), m};
+  const int n = work_slots(w, d, m, sl);
+  if (tl_work_live && memcmp(sig, tl_work_sig, sizeof sig) == 0) {
+    for (int i = 0; i < n; i++)
+      if (sl[i].zero) memset(*sl[i].p, 0, sizeof(double) * sl[i].n);
+  } else {
+    if (tl_work_live) work_free(w);
+    for (int i = 0; i < n; i++) *sl[i].p = (double *)calloc(sl[i].n ? sl[i].n : 1, sizeof(double));
+    memcpy(tl_work_sig, sig, sizeof sig);
+    tl_work_live = 1;
+  }
+  w->N = d->N; w->nx = d->nx; w->nw = d->ns + d->nu; w->nv = nvar_of(d); w->m = m;
+  return w;
 }
 
 /* evaluate every stage with derivatives at w->z; returns 0, or <0 */
@@ -806,8 +831,7 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
   if (orc_num_rows(d, &nh, &m) != 0) return -1;
   const int N = d->N, nx = d->nx, nv = nvar_of(d), nw = d->ns + d->nu;
   if (nx > NXM || nw > NWM || nv > NVM || N < 1) return -1;
-  orc_work W, *w = &W;
-  work_alloc(w, d, m);
+  orc_work *w = work_get(d, m);
   memcpy(w->z, x0, sizeof(double) * N * nv);
   memcpy(w->z, xinit, sizeof(double) * nx); /* x_1 = xinit (mpcModel.py:108 xinitidx) */
   memset(st, 0, sizeof *st);
@@ -1022,7 +1046,6 @@ done:
   memcpy(zout, w->z, sizeof(double) * N * nv);
   if (lam_out) memcpy(lam_out, w->lam, sizeof(double) * N * m);
   if (nu_out) memcpy(nu_out, w->nu, sizeof(double) * N * nx);
-  work_free(w);
   return 0;
 }
 

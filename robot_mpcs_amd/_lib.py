@@ -71,7 +71,7 @@ class RmpcScene(C.Structure):
 EXPORTED_SYMBOLS = [
     "rmpc_version", "rmpc_source_hash", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
     "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_warm_start", "rmpc_set_profiling", "rmpc_get_profile",
-    "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep",
+    "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep", "rmpc_spec_source", "rmpc_spec_name", "rmpc_spec_for",
     "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_advance_device", "rmpc_advance_device_flags", "rmpc_free_space_device",
 ]
 
@@ -83,7 +83,7 @@ def _source_hash():
     import hashlib
     root = os.path.dirname(_HERE)
     paths = [os.path.join(_HERE, "csrc", "rmpc_kernels.hip"), os.path.join(_HERE, "csrc", "rmpc_model.hpp"),
-             os.path.join(root, "include", "rmpc.h")]
+             os.path.join(_HERE, "csrc", "rmpc_spec_gen.hpp"), os.path.join(root, "include", "rmpc.h")]
     if not all(os.path.exists(p) for p in paths):
         return None
     h = hashlib.sha256()
@@ -91,6 +91,24 @@ def _source_hash():
         with open(p, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
+
+
+def spec_source(desc: dict, name: str) -> str:
+    """C++ text of the generated view of ``desc`` (``rmpc_spec_source``; needs no GPU)."""
+    L = load_library()
+    cd = make_desc(desc, 0)
+    n = L.rmpc_spec_source(C.byref(cd), name.encode(), None, 0)
+    if n < 0:
+        raise RmpcError("rmpc_spec_source failed: " + L.rmpc_last_error().decode())
+    buf = C.create_string_buffer(int(n))
+    L.rmpc_spec_source(C.byref(cd), name.encode(), buf, n)
+    return buf.value.decode()
+
+
+def spec_for(desc: dict) -> str:
+    """Name of the generated view ``rmpc_create`` would select for ``desc`` ("" = runtime row tables); no GPU needed."""
+    cd = make_desc(desc, 0)
+    return load_library().rmpc_spec_for(C.byref(cd)).decode()
 
 
 def source_hash() -> str:
@@ -142,6 +160,12 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_last_passes.argtypes = [C.c_void_p]
     L.rmpc_debug_sweep.restype = C.c_int
     L.rmpc_debug_sweep.argtypes = [C.c_void_p, C.c_int] + [dp] * 9
+    L.rmpc_spec_source.restype = C.c_int64
+    L.rmpc_spec_source.argtypes = [C.POINTER(RmpcDesc), C.c_char_p, C.c_char_p, C.c_int64]
+    L.rmpc_spec_name.restype = C.c_char_p
+    L.rmpc_spec_name.argtypes = [C.c_void_p]
+    L.rmpc_spec_for.restype = C.c_char_p
+    L.rmpc_spec_for.argtypes = [C.POINTER(RmpcDesc)]
     L.rmpc_debug_fused_stamps.restype = C.c_int
     L.rmpc_debug_fused_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
     L.rmpc_pack_scene_device.restype = C.c_int
@@ -265,6 +289,10 @@ class Solver:
         if rc != 0:
             raise RmpcError("rmpc_create failed: " + self._L.rmpc_last_error().decode())
         self._h = h
+
+    def spec_name(self) -> str:
+        """Name of the generated view this handle runs ("" = runtime row tables); ``rmpc_spec_name``."""
+        return self._L.rmpc_spec_name(self._h).decode()
 
     def close(self):
         if getattr(self, "_h", None):

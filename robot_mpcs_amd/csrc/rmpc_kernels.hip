@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "rmpc_model.hpp"
+#include "rmpc_spec_gen.hpp"   // generated views of the shipped configurations (scripts/gen_specs.py)
 
 namespace rmpc {
 
@@ -360,12 +361,49 @@ struct SweepIO {
   int warm;
 };
 // merit / KKT partial sums of one stage (order = enum Part)
-struct Partials { double f, th, logs, rstat, req, rineq, rcomp, sumc, minc, bad; };
+struct Partials {
+  double f, th, logs, rstat, req, rineq, rcomp, sumc, minc, bad;
+#ifdef RMPC_STAMPS
+  long long tk[4];   // development builds: cycles of the sections of the sweep
+#endif
+};
+#ifdef RMPC_STAMPS
+#define SW_STAMP(i) do { long long t_ = __builtin_amdgcn_s_memtime(); out.tk[i] = t_ - sw_t0; sw_t0 = t_; } while (0)
+#else
+#define SW_STAMP(i)
+#endif
 
-template <class C, int EARLY_MODE = -1, class RP = gdouble>
-__device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T, const SweepIO<RP> &io, const int k,
-                                           const bool first, const bool nostep, const double alpha, const double adual,
+// Order in which sweep_body takes the variables of a stage (positions 0 .. NV-1; the first NFIRST of them before
+// the kinematics: see EARLY in sweep_body).
+template <class C, bool EARLY>
+struct SweepOrder {
+  static constexpr int NFIRST = EARLY ? (C::NV - C::NQ - (C::NS > 0 ? 1 : 0)) : 0;
+  __host__ __device__ static constexpr int at(int p) {
+    int idx[C::NV] = {};
+    int n = 0;
+    if (EARLY) {
+      for (int j = C::NQ; j < C::NV; j++)
+        if (!(C::NS > 0 && j == C::NX)) idx[n++] = j;
+      for (int j = 0; j < C::NQ; j++) idx[n++] = j;
+      if (C::NS > 0) idx[n++] = C::NX;
+    } else {
+      for (int j = 0; j < C::NV; j++) idx[n++] = j;
+    }
+    return idx[p];
+  }
+};
+
+// FIRSTC: 1 / 0 = the first pass of a solve (or not) known at compile time, -1 = taken from first_rt.  The rows
+// branch on it; callers that can afford two copies of the body (every kernel here) pass it as a constant so that
+// the rows of a stage form one basic block and their requests are issued together.
+template <class C, int EARLY_MODE = -1, class RP = gdouble, class V = RtView, int FIRSTC = -1>
+__device__ __forceinline__ void sweep_body(const DevModel &M, const V &v, const SweepIO<RP> &io, const int k,
+                                           const bool first_rt, const bool nostep, const double alpha, const double adual,
                                            const double mu, Partials &out) {
+  const bool first = FIRSTC < 0 ? first_rt : (FIRSTC != 0);
+#ifdef RMPC_STAMPS
+  long long sw_t0 = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NU = C::NU, NV = C::NV;
   const int N = M.N;
   const unsigned loff = io.loff;
@@ -432,6 +470,47 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
     }
   }
   auto P = [&](int off) __attribute__((always_inline)) -> double { return pp[IDXL(off)]; };
+  // Request batching (generated views: PIPE).  One wavefront per SIMD hides no latency by itself, so the body issues
+  // what it will need well before it needs it: the objective parameters and every distance row's inputs here, the
+  // single-variable rows two variables ahead of the arithmetic (var_load / var_compute below).  With the runtime
+  // tables the requests stay where the arithmetic is, as before.
+  constexpr bool PIPE = V::SPEC;
+  double wuv[NU], wsv = 0.0, goalv[3] = {0, 0, 0}, wgoalv[3] = {0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < NU; j++) wuv[j] = P(v.off_wu() + j);
+  if constexpr (NS > 0) wsv = P(v.off_ws());
+  const double rbody = (v.off_r_body() >= 0) ? P(v.off_r_body()) : 0.0;
+  if (v.has_goal()) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { goalv[c] = P(v.off_goal() + c); wgoalv[c] = P(v.off_wgoal() + c); }
+  }
+  // inputs of a distance row: slack, multiplier, value and gradient at the current iterate, obstacle, weight
+  struct FkBuf { double tcv, lcv, gold, jo[NQ], op[4], wi; };
+  auto fk_load = [&](const int r, FkBuf &Bf) __attribute__((always_inline)) {
+    const int i = v.fk_row(r), kind = v.fk_kind(r), ob = v.fk_obst(r), fi = v.fk_idx(r);
+    Bf.tcv = tc[IDXL(i)]; Bf.lcv = lsrc[IDXLL(i)]; Bf.gold = gro[IDXL(i)];
+#pragma unroll
+    for (int a = 0; a < NQ; a++) Bf.jo[a] = jqo[IDXL(fi * NQ + a)];
+#pragma unroll
+    for (int c = 0; c < 4; c++) Bf.op[c] = 0.0;
+    if (kind == ROW_RADIAL) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) Bf.op[c] = P(v.off_obst() + 4 * ob + c);
+    } else if (kind == ROW_LINEAR) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) Bf.op[c] = P(v.off_lin() + 4 * ob + c);
+    }
+    Bf.wi = 0.0;
+    if (v.has_avoid() && v.fk_first(r)) Bf.wi = P(v.off_wconstr() + v.fk_mod(r));
+  };
+  constexpr int NFKC = []() { if constexpr (V::SPEC) return V::nfkrows() > 0 ? V::nfkrows() : 1; else return 1; }();
+  FkBuf fkb[NFKC];
+  if constexpr (PIPE) {
+    for_range<0, NFKC>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value;
+      if constexpr (r < V::nfkrows()) fk_load(r, fkb[r]);
+    });
+  }
 
   // ---- accumulators --------------------------------------------------------
   double gf[NV], q0[NV], q1[NV], rs[NV], Dg[NV], cs[NV];
@@ -455,24 +534,23 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
   double lprod = 1.0;
   int lexp = 0;
 
+  SW_STAMP(0);
   // ---- control effort and slack penalty (ObjectiveManager.py:28-42) ----------
 #pragma unroll
   for (int j = 0; j < NU; j++) {
-    const double wu = P(M.off_wu + j), u = z[NX + NS + j];
+    const double wu = wuv[j], u = z[NX + NS + j];
     f += wu * u * u;
     gf[NX + NS + j] += 2.0 * wu * u;
     Dg[NX + NS + j] += 2.0 * wu;
   }
   double sl = 0.0;
   if constexpr (NS > 0) {
-    const double ws = P(M.off_ws);
+    const double ws = wsv;
     sl = z[NX];
     f += ws * sl * sl;
     gf[NX] += 2.0 * ws * sl;
     Dg[NX] += 2.0 * ws;
   }
-  const double rbody = (M.off_r_body >= 0) ? P(M.off_r_body) : 0.0;
-
   // trial slack / multiplier of row i and their bookkeeping; returns sigma, ca, cb, lv
   struct RowW { double sig, ca, cb, lv; };
   // (gold, gdz: row value at the current iterate and J_i dz -- the slack / multiplier steps of the row are
@@ -513,49 +591,55 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
 
   // ---- single-variable rows: limits (general rows) and simple bounds, by variable ----
   // (generic lambda over a compile-time variable index: every array index stays a constant)
-  auto var_rows = [&](auto jc) __attribute__((always_inline)) {
+  struct VarBuf { double tcv[kVarRows], lcv[kVarRows], lim[kVarRows], wi[kVarRows]; };
+  auto var_load = [&](auto jc, VarBuf &Bv) __attribute__((always_inline)) {
     constexpr int j = decltype(jc)::value;
     // unconditional, clamped requests for the (up to) four rows of variable j
-    double tcv[kVarRows], lcv[kVarRows], lim[kVarRows];
 #pragma unroll
     for (int u = 0; u < kVarRows; u++) {
-      const int i = T.v_row[j][u];
+      const int i = v.v_row(j, u);
       const int ii = i >= 0 ? i : 0;
-      const int po = T.v_poff[j][u];
-      tcv[u] = tc[IDXL(ii)];
-      lcv[u] = lsrc[IDXLL(ii)];
+      const int po = v.v_poff(j, u);
+      Bv.tcv[u] = tc[IDXL(ii)];
+      Bv.lcv[u] = lsrc[IDXLL(ii)];
       const double pl = pp[IDXL(po >= 0 ? po : 0)];
-      lim[u] = po >= 0 ? pl : T.v_val[j][u];
+      Bv.lim[u] = po >= 0 ? pl : v.v_val(j, u);
+      Bv.wi[u] = 0.0;
+      if (i >= 0 && v.has_avoid() && v.v_first(j, u)) Bv.wi[u] = P(v.off_wconstr() + v.v_mod(j, u));
     }
+  };
+  auto var_compute = [&](auto jc, const VarBuf &Bv) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
 #pragma unroll
     for (int u = 0; u < kVarRows; u++) {
-      const int i = T.v_row[j][u];
+      const int i = v.v_row(j, u);
       if (i < 0) continue;  // uniform
-      const double sg = (double)T.v_sgn[j][u];
-      const bool soft = (NS > 0) && T.v_soft[j][u];
+      const double sg = (double)v.v_sgn(j, u);
+      const bool soft = (NS > 0) && v.v_soft(j, u);
       const bool neutral = (k == 0) && (j < NX) && !soft;  // constant of the problem at the pinned stage
-      const double h = neutral ? 1.0 : sg * (z[j] - lim[u]);
-      if (M.has_avoid && T.v_first[j][u] && !(k == 0 && j < NX)) {
-        const double wi = P(M.off_wconstr + T.v_mod[j][u]);
-        if (wi != 0.0) {
-          const double cN = (double)M.N * wi;
-          if (!(h > 0.0)) bad = 1;
-          const double ih = frcp(h);
-          f += cN * ih;
-          gf[j] += -cN * (ih * ih) * sg;
-          const double c2 = 2.0 * cN * (ih * ih * ih);
-          if (j < NQ) Qqq[j < NQ ? j : 0][j < NQ ? j : 0] += c2;
-          else Dg[j] += c2;
-        }
+      const double h = neutral ? 1.0 : sg * (z[j] - Bv.lim[u]);
+      if (v.has_avoid() && v.v_first(j, u)) {
+        // (selects, not a branch on the weight: a data-dependent branch would cut the stage's rows into
+        //  separate basic blocks and with them the batches of requests)
+        const double wi = Bv.wi[u];
+        const bool on = (wi != 0.0) && !(k == 0 && j < NX);
+        const double cN = (double)M.N * wi;
+        if (on && !(h > 0.0)) bad = 1;
+        const double ih = frcp(h);
+        f += on ? cN * ih : 0.0;
+        gf[j] += on ? -cN * (ih * ih) * sg : 0.0;
+        const double c2 = on ? 2.0 * cN * (ih * ih * ih) : 0.0;
+        if (j < NQ) Qqq[j < NQ ? j : 0][j < NQ ? j : 0] += c2;
+        else Dg[j] += c2;
       }
       double g = h;
       if constexpr (NS > 0) { if (soft) g += sl; }
-      if (T.v_poff[j][u] >= 0) grn[IDXL(i)] = g;  // general rows keep their value for k_step
+      if (v.v_poff(j, u) >= 0) grn[IDXL(i)] = g;  // general rows keep their value for k_step
       // the same row at the current iterate (what k_step read back or recomputed)
-      double gold = neutral ? 1.0 : sg * (zo[j] - lim[u]);
+      double gold = neutral ? 1.0 : sg * (zo[j] - Bv.lim[u]);
       double gdz = sg * dzo[j];
       if constexpr (NS > 0) { if (soft) { gold += zo[NX]; gdz += dzo[NX]; } }
-      const RowW rw = row_core(i, g, tcv[u], lcv[u], gold, gdz);
+      const RowW rw = row_core(i, g, Bv.tcv[u], Bv.lcv[u], gold, gdz);
       if (neutral) continue;
       q0[j] += sg * rw.ca;
       q1[j] += sg * rw.cb;
@@ -603,11 +687,41 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
   // start (the slack variable collects from every softened row and waits for the end): 1.2 KB less scratch
   // per lane, sweep 190 -> 139 us on cfg4.  The three-joint models do not spill and lose 7 % this way.
   constexpr bool EARLY = (EARLY_MODE >= 0) ? (CHAIN && EARLY_MODE != 0) : (CHAIN && (NQ > 3));
-  if constexpr (EARLY) {
-    for_range<NQ, NV>([&](auto jc) __attribute__((always_inline)) {
-      constexpr int j = decltype(jc)::value;
-      if constexpr (!(NS > 0 && j == NX)) { var_rows(jc); finalize_var(jc); }
-    });
+  using Ord = SweepOrder<C, EARLY>;
+  // positions [P0, P1) of the order; PIPE: the requests of a variable are issued two variables ahead (the first two
+  // of the range by the caller when PRE is set)
+  VarBuf vring[PIPE ? 3 : 1];
+  auto run_vars = [&](auto p0c, auto p1c, auto finc, auto prec) __attribute__((always_inline)) {
+    constexpr int P0 = decltype(p0c)::value, P1 = decltype(p1c)::value;
+    constexpr bool FIN = decltype(finc)::value, PRE = decltype(prec)::value;
+    if constexpr (P1 > P0) {
+      if constexpr (PIPE && !PRE) {
+        var_load(std::integral_constant<int, Ord::at(P0)>{}, vring[0]);
+        if constexpr (P0 + 1 < P1) var_load(std::integral_constant<int, Ord::at(P0 + 1 < P1 ? P0 + 1 : P0)>{}, vring[1]);
+      }
+      for_range<P0, P1>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int j = Ord::at(p);
+        if constexpr (PIPE) {
+          if constexpr (p + 2 < P1) var_load(std::integral_constant<int, Ord::at(p + 2 < P1 ? p + 2 : p)>{}, vring[(p + 2 - P0) % 3]);
+          __builtin_amdgcn_sched_barrier(0);
+          var_compute(std::integral_constant<int, j>{}, vring[(p - P0) % 3]);
+        } else {
+          var_load(std::integral_constant<int, j>{}, vring[0]);
+          var_compute(std::integral_constant<int, j>{}, vring[0]);
+        }
+        if constexpr (FIN) finalize_var(std::integral_constant<int, j>{});
+      });
+    }
+  };
+  using TrueT = std::integral_constant<bool, true>;
+  using FalseT = std::integral_constant<bool, false>;
+  run_vars(std::integral_constant<int, 0>{}, std::integral_constant<int, Ord::NFIRST>{}, TrueT{}, FalseT{});
+  // (no variable goes first: the requests of the first two variables leave before the kinematics)
+  constexpr bool PRE2 = PIPE && (Ord::NFIRST == 0);
+  if constexpr (PRE2) {
+    var_load(std::integral_constant<int, Ord::at(0)>{}, vring[0]);
+    if constexpr (NV > 1) var_load(std::integral_constant<int, Ord::at(NV > 1 ? 1 : 0)>{}, vring[1]);
   }
 
   // ---- kinematics, GoalReaching and the FK rows, slot by slot -------------------
@@ -616,17 +730,20 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
     double q[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; j++) q[j] = z[j];
-    kin.compute(M, T, q);
+    kin.compute(v, q);
   }
   auto do_slot = [&](auto slc) __attribute__((always_inline)) {
     constexpr int SL = decltype(slc)::value;
-    if (SL >= T.nslots) return;
+    if constexpr (V::SPEC) {
+      if constexpr (SL >= V::nslots()) return;
+    }
+    if (SL >= v.nslots()) return;
     Vec3 J[NQ];
-    const Vec3 Pt = kin.template point<SL>(M, T, J);
-    if (SL == 0 && M.has_goal) {
+    const Vec3 Pt = kin.template point<SL>(v, J);
+    if (SL == 0 && v.has_goal()) {
       // GoalReaching (goal_reaching.py:19-33), Gauss-Newton Hessian
-      const double e0 = Pt.x - P(M.off_goal), e1 = Pt.y - P(M.off_goal + 1), e2 = Pt.z - P(M.off_goal + 2);
-      const double w0 = P(M.off_wgoal), w1 = P(M.off_wgoal + 1), w2 = P(M.off_wgoal + 2);
+      const double e0 = Pt.x - goalv[0], e1 = Pt.y - goalv[1], e2 = Pt.z - goalv[2];
+      const double w0 = wgoalv[0], w1 = wgoalv[1], w2 = wgoalv[2];
       f += w0 * e0 * e0 + w1 * e1 * e1 + w2 * e2 * e2;
 #pragma unroll
       for (int a = 0; a < NQ; a++) {
@@ -636,37 +753,31 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
           Qqq[a][c] += 2.0 * (w0 * J[a].x * J[c].x + w1 * J[a].y * J[c].y + w2 * J[a].z * J[c].z);
       }
     }
-    for (int r = T.slot_row_begin[SL]; r < T.slot_row_begin[SL + 1]; r++) {
-      const int i = T.fk_row[r], kind = T.fk_kind[r], ob = T.fk_obst[r], mi = T.fk_mod[r];
-      // requests first, arithmetic after
-      const int fi = T.fk_idx[r];
-      const double tcv = tc[IDXL(i)], lcv = lsrc[IDXLL(i)], gold = gro[IDXL(i)];
+    auto fk_row_body = [&](const int r, const FkBuf &Bf) __attribute__((always_inline)) {
+      const int i = v.fk_row(r), kind = v.fk_kind(r);
+      const int fi = v.fk_idx(r);
+      const double tcv = Bf.tcv, lcv = Bf.lcv, gold = Bf.gold;
       double gdz = 0.0;
       {
-        double jo[NQ];
 #pragma unroll
-        for (int a = 0; a < NQ; a++) jo[a] = jqo[IDXL(fi * NQ + a)];
-#pragma unroll
-        for (int a = 0; a < NQ; a++) gdz += jo[a] * dzo[a];
+        for (int a = 0; a < NQ; a++) gdz += Bf.jo[a] * dzo[a];
         if constexpr (NS > 0) gdz += dzo[NX];
       }
       double gq[NQ];
       double h, cinv = 0.0;
       if (kind == ROW_RADIAL) {
         // ||fk_l(q) - c_i|| - r_i - r_body (mpcBase.py:82-101)
-        const int o = M.off_obst + 4 * ob;
-        const Vec3 dv = {Pt.x - P(o), Pt.y - P(o + 1), Pt.z - P(o + 2)};
+        const Vec3 dv = {Pt.x - Bf.op[0], Pt.y - Bf.op[1], Pt.z - Bf.op[2]};
         const double dist = sqrt(dot(dv, dv));
-        h = dist - P(o + 3) - rbody;
+        h = dist - Bf.op[3] - rbody;
         cinv = 1.0 / dist;
 #pragma unroll
         for (int a = 0; a < NQ; a++) gq[a] = dot(dv, J[a]) * cinv;
       } else if (kind == ROW_LINEAR) {
         // |a.fk_l(q) + d| / ||a|| - r_body (LinearConstraints.py:25-40, utils.py:48-52)
-        const int o = M.off_lin + 4 * ob;
-        const Vec3 av = {P(o), P(o + 1), P(o + 2)};
+        const Vec3 av = {Bf.op[0], Bf.op[1], Bf.op[2]};
         const double nrm = sqrt(dot(av, av));
-        const double sd = dot(av, Pt) + P(o + 3);
+        const double sd = dot(av, Pt) + Bf.op[3];
         const double sgn = sd < 0 ? -1.0 : 1.0;
         h = fabs(sd) / nrm - rbody;
 #pragma unroll
@@ -688,22 +799,21 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
         for (int a = 0; a < NQ; a++) gq[a] = 0.0;
       }
       double cw = 0.0;
-      if (M.has_avoid && T.fk_first[r] && k != 0) {
+      if (v.has_avoid() && v.fk_first(r)) {
         // inverse-barrier objective N w_i / h on the first row of a module (constraint_avoidance.py:22-31)
-        const double wi = P(M.off_wconstr + mi);
-        if (wi != 0.0) {
-          const double cN = (double)M.N * wi;
-          if (!(h > 0.0)) bad = 1;
-          const double ih = frcp(h);
-          f += cN * ih;
-          const double c1 = -cN * (ih * ih), c2 = 2.0 * cN * (ih * ih * ih);
-          cw = cN * (ih * ih);
+        const double wi = Bf.wi;
+        const bool on = (wi != 0.0) && (k != 0);   // (selects: see the single-variable rows)
+        const double cN = (double)M.N * wi;
+        if (on && !(h > 0.0)) bad = 1;
+        const double ih = frcp(h);
+        f += on ? cN * ih : 0.0;
+        const double c1 = on ? -cN * (ih * ih) : 0.0, c2 = on ? 2.0 * cN * (ih * ih * ih) : 0.0;
+        cw = on ? cN * (ih * ih) : 0.0;
 #pragma unroll
-          for (int a = 0; a < NQ; a++) {
-            gf[a] += c1 * gq[a];
+        for (int a = 0; a < NQ; a++) {
+          gf[a] += c1 * gq[a];
 #pragma unroll
-            for (int c = a; c < NQ; c++) Qqq[a][c] += c2 * gq[a] * gq[c];
-          }
+          for (int c = a; c < NQ; c++) Qqq[a][c] += c2 * gq[a] * gq[c];
         }
       }
       double g = h;
@@ -730,13 +840,24 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
       if constexpr (C::CURV) {
         // exact Hessian of the distance rows when the kinematics are affine in q:
         // grad^2 h = (J^T J - g g^T) / dist, weighted by the multiplier and the inverse-barrier term
-        if (M.use_curv && kind != ROW_LINEAR) {
-          const double wgt = (rw.lv + cw) * cinv;
+        // (weight selected, not branched on: the rows of the slot stay one basic block)
+        const double wgt = (M.use_curv && kind != ROW_LINEAR) ? (rw.lv + cw) * cinv : 0.0;
 #pragma unroll
-          for (int a = 0; a < NQ; a++)
+        for (int a = 0; a < NQ; a++)
 #pragma unroll
-            for (int c = a; c < NQ; c++) Cqq[a][c] += wgt * (dot(J[a], J[c]) - gq[a] * gq[c]);
-        }
+          for (int c = a; c < NQ; c++) Cqq[a][c] += wgt * (dot(J[a], J[c]) - gq[a] * gq[c]);
+      }
+    };
+    if constexpr (V::SPEC) {
+      // generated view: the rows of the slot are known at compile time -- straight-line code
+      for_range<0, V::nfkrows()>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        if constexpr (r >= V::slot_row_begin(SL) && r < V::slot_row_begin(SL + 1)) fk_row_body(r, fkb[r]);
+      });
+    } else {
+      for (int r = v.slot_row_begin(SL); r < v.slot_row_begin(SL + 1); r++) {
+        fk_load(r, fkb[0]);   // requests first, arithmetic after
+        fk_row_body(r, fkb[0]);
       }
     }
   };
@@ -745,14 +866,12 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
   do_slot(std::integral_constant<int, 2>{});
   do_slot(std::integral_constant<int, 3>{});
 
+  SW_STAMP(1);
   // ---- the remaining single-variable rows -----------------------------------------------
-  if constexpr (EARLY) {
-    for_range<0, NQ>(var_rows);
-    if constexpr (NS > 0) var_rows(std::integral_constant<int, NX>{});
-  } else {
-    for_range<0, NV>(var_rows);
-  }
+  run_vars(std::integral_constant<int, Ord::NFIRST>{}, std::integral_constant<int, NV>{}, FalseT{},
+           std::integral_constant<bool, PRE2>{});
 
+  SW_STAMP(2);
   // ---- dynamics defect and stationarity -------------------------------------------
   double req = 0.0;
   if constexpr (CHAIN) {
@@ -766,6 +885,11 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
         req = fmax(req, fabs(r));
         theta += fabs(r);
       }
+    } else {
+      // (the last stage has no defect, but the recursion reads the entries -- times a zero cost-to-go; records in
+      //  LDS start from whatever the previous kernel left there, and 0 * NaN is not 0)
+#pragma unroll
+      for (int j = 0; j < NX; j++) rec[C::R_RC + j] = 0.0;
     }
     if constexpr (EARLY) {
       for_range<0, NQ>(finalize_var);
@@ -809,6 +933,12 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
         req = fmax(req, fabs(r));
         theta += fabs(r);
       }
+    } else {
+      // (see the holonomic chain: every entry the recursion reads is written)
+#pragma unroll
+      for (int i = 0; i < 35; i++) rec[C::R_A5 + i] = 0.0;
+#pragma unroll
+      for (int j = 0; j < NX; j++) rec[C::R_RC + j] = 0.0;
     }
 #pragma unroll
     for (int j = 0; j < NV; j++) {
@@ -852,11 +982,12 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const DevTables &T
   rec[C::R_ZERO] = 0.0;
   const double logsum = log(lprod) + 0.6931471805599453094 * (double)lexp;
   if (!isfinite(f) || !isfinite(theta) || !isfinite(logsum)) bad = 1;
+  SW_STAMP(3);
   out.f = f; out.th = theta; out.logs = logsum; out.rstat = rstat; out.req = req; out.rineq = rineq;
   out.rcomp = rcomp; out.sumc = sumc; out.minc = minc; out.bad = (double)bad;
 }
 
-template <class C>
+template <class C, class V>
 __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
                                                const int B, const int first, const int warm) {
   const int gid = blockIdx.x * kSweepBlock + threadIdx.x;
@@ -892,7 +1023,9 @@ __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevMo
     adual = __longlong_as_double((long long)W.amin_d[b]);
   }
   Partials pt;
-  sweep_body<C>(M, *Tp, io, k, first != 0, nostep, alpha, adual, W.mu[b], pt);
+  const V v(M, *Tp);
+  if (first) sweep_body<C, -1, gdouble, V, 1>(M, v, io, k, true, nostep, alpha, adual, W.mu[b], pt);
+  else sweep_body<C, -1, gdouble, V, 0>(M, v, io, k, false, nostep, alpha, adual, W.mu[b], pt);
   const unsigned loff = io.loff;
   const size_t SS = io.SS;
   W.part[IDXL(P_F)] = pt.f;
@@ -1177,14 +1310,13 @@ struct FusedSlots {
 };
 
 template <class C, int LPI, bool SLOTS = false, class RP = gdouble>
-__device__ __forceinline__ bool riccati_recursion(const DevModel &M, const double mu, const bool usec, const int lane,
+__device__ __forceinline__ bool riccati_recursion(const int N, const double dt, const double mu, const bool usec, const int lane,
                                                   ldouble *const img, const RP *const rb, gdouble *const kpb,
                                                   const int kps, const StepOut<RP> so, ldouble *const slots = nullptr) {
   // SLOTS: rb == slots (records), gains go to the slots as well (kpb unused)
   constexpr int GS = FusedSlots<C>::GS;
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NV = C::NV, NW = C::NW;
   constexpr bool DD = (C::ROBOT == RMPC_ROBOT_DIFFDRIVE);
-  const int N = M.N;
   const double cwt = usec ? 1.0 : 0.0;  // Cqq is zero-filled when the model does not use it
   // ---- LDS images -------------------------------------------------------------------------
   // img = [K | kff | P (upper triangle) | p | rc]: what the forward pass needs of a stage, contiguous in
@@ -1200,7 +1332,7 @@ __device__ __forceinline__ bool riccati_recursion(const DevModel &M, const doubl
     const int lo = i < j ? i : j, hi = i < j ? j : i;
     return lo * NX - lo * (lo - 1) / 2 + (hi - lo);
   };
-  const double h = M.dt, h2 = 0.5 * M.dt * M.dt;
+  const double h = dt, h2 = 0.5 * dt * dt;
 
   // ([A | B] of the holonomic chain is constant, A = [I hI; 0 I], B = [h2 I; h I] on the u columns: every
   //  product with it is written out in closed form below and sAB is used by the diff-drive model only)
@@ -1844,7 +1976,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   __shared__ double lds[IPB * IPW][RicLds<C, LPI>::LDSW];
   StepOut<gdouble> so;
   so.dz = (gdouble *)(W.dz + b); so.nunew = (gdouble *)(W.nunew + b); so.SS = (size_t)N * W.Bp; so.KS = (size_t)W.Bp;
-  const bool chol_ok = riccati_recursion<C, LPI, false, gdouble>(M, mu, usec, lane, (ldouble *)lds[wv],
+  const bool chol_ok = riccati_recursion<C, LPI, false, gdouble>(M.N, M.dt, mu, usec, lane, (ldouble *)lds[wv],
                                                                  (const gdouble *)(W.R + (size_t)b * N * C::RS),
                                                                  (gdouble *)(W.KP + (size_t)b * N * W.kps), W.kps, so);
   if (L0) {
@@ -1876,8 +2008,8 @@ struct StepIO {
 };
 
 // ap, ad: fraction-to-the-boundary step lengths of this stage (1 when no row binds); gphi: its merit slope partial
-template <class C, class RP = gdouble>
-__device__ __forceinline__ void step_body(const DevTables &T, const StepIO<RP> &io, const int k, const double mu,
+template <class C, class RP = gdouble, class V = RtView>
+__device__ __forceinline__ void step_body(const V &v, const StepIO<RP> &io, const int k, const double mu,
                                           double &ap_out, double &ad_out, double &gphi_out) {
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NV = C::NV;
   const unsigned loff = io.loff;
@@ -1910,8 +2042,8 @@ __device__ __forceinline__ void step_body(const DevTables &T, const StepIO<RP> &
     gphi -= mu * dt * itv;
   };
   // FK rows
-  for (int r = 0; r < T.nfkrows; r++) {
-    const int i = T.fk_row[r], fi = T.fk_idx[r];
+  auto fk_row_body = [&](const int r) __attribute__((always_inline)) {
+    const int i = v.fk_row(r), fi = v.fk_idx(r);
     const double g = grow[IDXL(i)], tv = tc[IDXL(i)], lv = lc[IDXL(i)];
     double jq[NQ];
 #pragma unroll
@@ -1921,6 +2053,11 @@ __device__ __forceinline__ void step_body(const DevTables &T, const StepIO<RP> &
     for (int a = 0; a < NQ; a++) gdz += jq[a] * dz[a];
     if constexpr (NS > 0) gdz += dz[NX];
     row(i, gdz, g, tv, lv);
+  };
+  if constexpr (V::SPEC) {
+    for_range<0, V::nfkrows()>([&](auto rc) __attribute__((always_inline)) { fk_row_body(decltype(rc)::value); });
+  } else {
+    for (int r = 0; r < v.nfkrows(); r++) fk_row_body(r);
   }
   // single-variable rows, by variable (unconditional clamped requests, see sweep_body)
 #pragma unroll
@@ -1928,27 +2065,27 @@ __device__ __forceinline__ void step_body(const DevTables &T, const StepIO<RP> &
     double tv[kVarRows], lv[kVarRows], gv[kVarRows];
 #pragma unroll
     for (int u = 0; u < kVarRows; u++) {
-      const int i = T.v_row[j][u];
+      const int i = v.v_row(j, u);
       const int ii = i >= 0 ? i : 0;
-      const bool general = T.v_poff[j][u] >= 0;
+      const bool general = v.v_poff(j, u) >= 0;
       tv[u] = tc[IDXL(ii)];
       lv[u] = lc[IDXL(ii)];
       const double gl = grow[IDXL(general ? ii : 0)];
-      gv[u] = general ? gl : ((k == 0 && j < NX) ? 1.0 : (double)T.v_sgn[j][u] * (z[j] - T.v_val[j][u]));
+      gv[u] = general ? gl : ((k == 0 && j < NX) ? 1.0 : (double)v.v_sgn(j, u) * (z[j] - v.v_val(j, u)));
     }
 #pragma unroll
     for (int u = 0; u < kVarRows; u++) {
-      const int i = T.v_row[j][u];
+      const int i = v.v_row(j, u);
       if (i < 0) continue;
-      double gdz = (double)T.v_sgn[j][u] * dz[j];
-      if constexpr (NS > 0) { if (T.v_soft[j][u]) gdz += dz[NX]; }
+      double gdz = (double)v.v_sgn(j, u) * dz[j];
+      if constexpr (NS > 0) { if (v.v_soft(j, u)) gdz += dz[NX]; }
       row(i, gdz, gv[u], tv[u], lv[u]);
     }
   }
   ap_out = ap; ad_out = ad; gphi_out = gphi;
 }
 
-template <class C>
+template <class C, class V>
 __global__ __launch_bounds__(kSweepBlock) void k_step(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
                                               const int B) {
   const int gid = blockIdx.x * kSweepBlock + threadIdx.x;
@@ -1966,7 +2103,8 @@ __global__ __launch_bounds__(kSweepBlock) void k_step(const DevModel M, const De
   io.loff = (unsigned)k * (unsigned)W.Bp + (unsigned)b;
   io.SSd = io.SS; io.loffd = io.loff;
   double ap, ad, gphi;
-  step_body<C>(*Tp, io, k, W.mu[b], ap, ad, gphi);
+  const V v(M, *Tp);
+  step_body<C, gdouble, V>(v, io, k, W.mu[b], ap, ad, gphi);
   // partial minima -> per-instance step lengths (min is order independent: deterministic)
   atomicMin(&W.amin_p[b], (unsigned long long)__double_as_longlong(ap));
   atomicMin(&W.amin_d[b], (unsigned long long)__double_as_longlong(ad));
@@ -2012,19 +2150,42 @@ struct FusedWs {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
   } while (0)
 
-template <class C, bool REC_LDS, int IPW>
-__global__ __launch_bounds__(32 * IPW, IPW == 1 ? 2 : 1) void k_fused(const DevModel M, const DevTables *__restrict__ Tp, const FusedWs F, const int B,
+// The phases of the fused kernel are real functions, not inlined bodies: one 500-register function with the sweep,
+// the recursion and the step phase inside lets the register allocator spill the loop-carried values of the
+// recursion's stage loop to make room for the sweep's straight-line code (measured with the generated views:
+// recursion 83 k -> 125 k cycles per pass).  As callees every phase gets the whole register file to itself and the
+// few words that live across a call are saved once around it.
+#ifdef RMPC_NOINLINE_OFF
+#define RMPC_PHASE __forceinline__
+#else
+#define RMPC_PHASE __noinline__
+#endif
+template <class C>
+__device__ RMPC_PHASE bool fused_recursion_lds(const int N, const double dt, const double mu, const bool usec, const int lane,
+                                               ldouble *const work, ldouble *const slots, const StepOut<ldouble> so) {
+  return riccati_recursion<C, kFusedStages, true, ldouble>(N, dt, mu, usec, lane, work, slots, nullptr, 0, so, slots);
+}
+template <class C>
+__device__ RMPC_PHASE bool fused_recursion_mem(const int N, const double dt, const double mu, const bool usec, const int lane,
+                                               ldouble *const work, const gdouble *const grec, gdouble *const kpb,
+                                               const int kps, const StepOut<gdouble> so) {
+  return riccati_recursion<C, kFusedStages, false, gdouble>(N, dt, mu, usec, lane, work, grec, kpb, kps, so);
+}
+
+template <class C, bool REC_LDS, class V>
+__global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTables *__restrict__ Tp, const FusedWs F, const int B,
                                               const double *__restrict__ xinit, const double *__restrict__ x0,
                                               const double *__restrict__ params, double *__restrict__ zout,
                                               int *__restrict__ exitflag, int *__restrict__ iters_out,
                                               double *__restrict__ kkt, double *__restrict__ obj, const int max_passes,
                                               const int warm_mode) {
   constexpr int LPI = kFusedStages;
+  constexpr int IPW = 2;   // instances per wavefront
   constexpr int NX = C::NX, NV = C::NV;
-  const DevTables &T = *Tp;
+  const V v(M, *Tp);
   const int half = threadIdx.x / LPI;
   const int k = threadIdx.x & (LPI - 1);       // stage of this lane; also its lane index inside the instance
-  const int bi = blockIdx.x * IPW + half;   // IPW instances per wavefront (1: the upper 32 lanes are switched off)
+  const int bi = blockIdx.x * IPW + half;
   const bool valid = bi < B;
   const size_t b = valid ? bi : B - 1;          // clamped: addresses stay legal, nothing is written for !valid
   const int N = M.N;
@@ -2083,6 +2244,7 @@ __global__ __launch_bounds__(32 * IPW, IPW == 1 ? 2 : 1) void k_fused(const DevM
 
 #ifdef RMPC_STAMPS
   long long st_sweep = 0, st_dec = 0, st_ric = 0, st_step = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
+  long long st_sw[4] = {0, 0, 0, 0};
 #define STAMP_A() st_a = __builtin_amdgcn_s_memtime()
 #define STAMP_B(acc) do { st_b = __builtin_amdgcn_s_memtime(); acc += st_b - st_a; st_a = st_b; } while (0)
 #else
@@ -2097,6 +2259,9 @@ __global__ __launch_bounds__(32 * IPW, IPW == 1 ? 2 : 1) void k_fused(const DevM
     STAMP_A();
     // ---- sweep: trial point, model functions, condensing, stage partials -------------------------------
     Partials q = {0, 0, 0, 0, 0, 0, 0, 0, 1e300, 0};
+#ifdef RMPC_STAMPS
+    q.tk[0] = q.tk[1] = q.tk[2] = q.tk[3] = 0;
+#endif
     if (act && stage) {
       const int cur = s.cur, nxt = cur ^ 1;
       using RP = typename std::conditional<REC_LDS, ldouble, gdouble>::type;
@@ -2123,7 +2288,8 @@ __global__ __launch_bounds__(32 * IPW, IPW == 1 ? 2 : 1) void k_fused(const DevM
         alpha = ldexp(s.amin_p, -s.ls);
         adual = s.amin_d;
       }
-      sweep_body<C, EM, RP>(M, T, io, k, first, nostep, alpha, adual, s.mu, q);
+      if (first) sweep_body<C, EM, RP, V, 1>(M, v, io, k, true, nostep, alpha, adual, s.mu, q);
+      else sweep_body<C, EM, RP, V, 0>(M, v, io, k, false, nostep, alpha, adual, s.mu, q);
     }
     Reduced r;
     r.f = wave_sum<LPI>(q.f); r.th = wave_sum<LPI>(q.th); r.lgs = wave_sum<LPI>(q.logs); r.sumc = wave_sum<LPI>(q.sumc);
@@ -2133,6 +2299,9 @@ __global__ __launch_bounds__(32 * IPW, IPW == 1 ? 2 : 1) void k_fused(const DevM
     r.gphi = first ? 0.0 : gphi_sum;
     GSYNC();   // trial point and records are complete before any lane reads another lane's part
     STAMP_B(st_sweep);
+#ifdef RMPC_STAMPS
+    for (int i = 0; i < 4; i++) st_sw[i] += __builtin_amdgcn_readfirstlane((int)q.tk[i]);
+#endif
     // ---- decisions, then a new step when the trial was accepted --------------------------------------
     bool usec = false;
     bool recurse = false;
@@ -2143,11 +2312,11 @@ __global__ __launch_bounds__(32 * IPW, IPW == 1 ? 2 : 1) void k_fused(const DevM
       if constexpr (REC_LDS) {
         StepOut<ldouble> so;
         so.dz = slots + DZ_OFF; so.nunew = slots + DZ_OFF + NV; so.SS = 1; so.KS = GS;
-        ok = riccati_recursion<C, LPI, true, ldouble>(M, s.mu, usec, k, work, slots, nullptr, 0, so, slots);
+        ok = fused_recursion_lds<C>(M.N, M.dt, s.mu, usec, k, work, slots, so);
       } else {
         StepOut<gdouble> so;
         so.dz = pdz; so.nunew = pnn; so.SS = S; so.KS = 1;
-        ok = riccati_recursion<C, LPI, false, gdouble>(M, s.mu, usec, k, work, grec, kpb, F.kps, so);
+        ok = fused_recursion_mem<C>(M.N, M.dt, s.mu, usec, k, work, grec, kpb, F.kps, so);
       }
       inst_after_recursion(s, ok, usec);
     }
@@ -2165,7 +2334,7 @@ __global__ __launch_bounds__(32 * IPW, IPW == 1 ? 2 : 1) void k_fused(const DevM
       io.SS = S; io.loff = (unsigned)k;
       if constexpr (REC_LDS) { io.dz = slots + DZ_OFF; io.SSd = 1; io.loffd = (unsigned)(k * GS); }
       else { io.dz = pdz; io.SSd = S; io.loffd = (unsigned)k; }
-      step_body<C, RP>(T, io, k, s.mu, ap, ad, gp);
+      step_body<C, RP, V>(v, io, k, s.mu, ap, ad, gp);
     }
     ap = wave_min<LPI>(ap); ad = wave_min<LPI>(ad); gp = wave_sum<LPI>(gp);
     if (stepping) {
@@ -2178,6 +2347,10 @@ __global__ __launch_bounds__(32 * IPW, IPW == 1 ? 2 : 1) void k_fused(const DevM
 #ifdef RMPC_STAMPS
   if (threadIdx.x == 0) {
     long long *o = F.stamps + (size_t)blockIdx.x * 8;
+    {
+      long long *o2 = F.stamps + (size_t)(gridDim.x + blockIdx.x) * 8;   // second half of the array: sweep sections
+      for (int i = 0; i < 4; i++) o2[i] = st_sw[i];
+    }
     o[0] = st_sweep; o[1] = st_dec; o[2] = st_ric; o[3] = st_step; o[4] = __builtin_amdgcn_s_memtime() - st_t0; o[5] = pass;
     o[6] = st_t0;
   }
@@ -2407,7 +2580,7 @@ struct rmpc_handle {
   int warm_mode = 0;        // rmpc_set_warm_start
   bool have_duals = false;  // the warm-start arrays hold the multipliers of a finished solve of duals_B instances
   int duals_B = 0;
-  int fused_ipw = 2;    // instances per wavefront of the fused kernel (development switch RMPC_FUSED_IPW)
+  int spec = -1;        // generated view whose tables equal this descriptor's (rmpc_spec_gen.hpp), -1: runtime tables
   bool fused = false;   // this model runs the fused kernel (small models, N <= 32); the pass kernels otherwise
   FusedWs F;
   int *h_passes = nullptr;  // pinned
@@ -2657,6 +2830,117 @@ static int build_model(const rmpc_desc &d, DevModel &M, std::string &err) {
   return 0;
 }
 
+// ---- generated views (rmpc_spec_gen.hpp) --------------------------------------------------
+// Source text of the view of one descriptor: the accessors of RtView as constexpr functions over literal tables
+// (doubles as hex floats: exact).  scripts/gen_specs.py writes rmpc_spec_gen.hpp from it for the shipped
+// configurations; the library is then built with those views next to the runtime one.
+static std::string spec_source(const rmpc_desc &d, const DevModel &M, const DevTables &T, const std::string &name) {
+  std::string o;
+  char buf[128];
+  auto fi = [&](int v) { snprintf(buf, sizeof buf, "%d", v); return std::string(buf); };
+  auto fd = [&](double v) { snprintf(buf, sizeof buf, "%a", v); return std::string(buf); };
+  auto scalar = [&](const char *nm, int v) {
+    o += "  __host__ __device__ static constexpr int " + std::string(nm) + "() { return " + fi(v) + "; }\n";
+  };
+  auto arr1 = [&](const char *nm, const int *p, int n) {
+    o += "  __host__ __device__ static constexpr int " + std::string(nm) + "(int i) { constexpr int t[" + fi(n) + "] = {";
+    for (int i = 0; i < n; i++) o += (i ? ", " : "") + fi(p[i]);
+    o += "}; return t[i]; }\n";
+  };
+  auto arr2i = [&](const char *nm, const int *p, int n0, int n1) {
+    o += "  __host__ __device__ static constexpr int " + std::string(nm) + "(int i, int j) { constexpr int t[" + fi(n0) + "][" + fi(n1) + "] = {";
+    for (int i = 0; i < n0; i++) {
+      o += (i ? ", {" : "{");
+      for (int j = 0; j < n1; j++) o += (j ? ", " : "") + fi(p[i * n1 + j]);
+      o += "}";
+    }
+    o += "}; return t[i][j]; }\n";
+  };
+  auto arr2d = [&](const char *nm, const double *p, int n0, int n1) {
+    o += "  __host__ __device__ static constexpr double " + std::string(nm) + "(int i, int j) { constexpr double t[" + fi(n0) + "][" + fi(n1) + "] = {";
+    for (int i = 0; i < n0; i++) {
+      o += (i ? ", {" : "{");
+      for (int j = 0; j < n1; j++) o += (j ? ", " : "") + fd(p[i * n1 + j]);
+      o += "}";
+    }
+    o += "}; return t[i][j]; }\n";
+  };
+  o += "struct " + name + " {\n  static constexpr bool SPEC = true;\n";
+  o += "  static constexpr int ROBOT = " + fi(d.robot) + ", NQ = " + fi(d.n) + ", NS = " + fi(d.ns) + ";\n";
+  o += "  __host__ __device__ " + name + "() {}\n  __host__ __device__ " + name + "(const DevModel &, const DevTables &) {}\n";
+  scalar("nslots", T.nslots);
+  arr1("slot_fa", T.slot_fa, kMaxSlots);
+  arr1("slot_fb", T.slot_fb, kMaxSlots);
+  arr1("slot_row_begin", T.slot_row_begin, kMaxSlots + 1);
+  scalar("nfkrows", T.nfkrows);
+  arr1("fk_row", T.fk_row, kMaxFkRows);
+  arr1("fk_kind", T.fk_kind, kMaxFkRows);
+  arr1("fk_obst", T.fk_obst, kMaxFkRows);
+  arr1("fk_mod", T.fk_mod, kMaxFkRows);
+  arr1("fk_first", T.fk_first, kMaxFkRows);
+  arr1("fk_idx", T.fk_idx, kMaxFkRows);
+  arr2i("v_row", &T.v_row[0][0], RMPC_NV_MAX, kVarRows);
+  arr2i("v_sgn", &T.v_sgn[0][0], RMPC_NV_MAX, kVarRows);
+  arr2i("v_poff", &T.v_poff[0][0], RMPC_NV_MAX, kVarRows);
+  arr2i("v_soft", &T.v_soft[0][0], RMPC_NV_MAX, kVarRows);
+  arr2i("v_mod", &T.v_mod[0][0], RMPC_NV_MAX, kVarRows);
+  arr2i("v_first", &T.v_first[0][0], RMPC_NV_MAX, kVarRows);
+  arr2d("v_val", &T.v_val[0][0], RMPC_NV_MAX, kVarRows);
+  scalar("off_r_body", M.off_r_body); scalar("off_obst", M.off_obst); scalar("off_lin", M.off_lin);
+  scalar("off_wu", M.off_wu); scalar("off_goal", M.off_goal); scalar("off_wgoal", M.off_wgoal);
+  scalar("off_wconstr", M.off_wconstr); scalar("off_ws", M.off_ws);
+  scalar("has_goal", M.has_goal); scalar("has_avoid", M.has_avoid);
+  arr1("joint_type", M.joint_type, RMPC_MAX_JOINTS);
+  arr2d("joint_xyz", &M.joint_xyz[0][0], RMPC_MAX_JOINTS, 3);
+  arr2d("joint_rot", &M.joint_rot[0][0], RMPC_MAX_JOINTS, 9);
+  arr2d("joint_axis", &M.joint_axis[0][0], RMPC_MAX_JOINTS, 3);
+  arr2d("dd_off", &M.dd_off[0][0], RMPC_MAX_JOINTS, 3);
+  o += "};\n";
+  return o;
+}
+
+// true when every accessor of the generated view S returns what the runtime tables hold
+template <class S>
+static bool spec_matches(const rmpc_desc &d, const DevModel &M, const DevTables &T) {
+  if (S::ROBOT != d.robot || S::NQ != d.n || S::NS != d.ns) return false;
+  bool ok = S::nslots() == T.nslots && S::nfkrows() == T.nfkrows;
+  for (int i = 0; i < kMaxSlots; i++) ok = ok && S::slot_fa(i) == T.slot_fa[i] && S::slot_fb(i) == T.slot_fb[i];
+  for (int i = 0; i <= kMaxSlots; i++) ok = ok && S::slot_row_begin(i) == T.slot_row_begin[i];
+  for (int i = 0; i < kMaxFkRows; i++)
+    ok = ok && S::fk_row(i) == T.fk_row[i] && S::fk_kind(i) == T.fk_kind[i] && S::fk_obst(i) == T.fk_obst[i] &&
+         S::fk_mod(i) == T.fk_mod[i] && S::fk_first(i) == T.fk_first[i] && S::fk_idx(i) == T.fk_idx[i];
+  for (int j = 0; j < RMPC_NV_MAX; j++)
+    for (int u = 0; u < kVarRows; u++)
+      ok = ok && S::v_row(j, u) == T.v_row[j][u] && S::v_sgn(j, u) == T.v_sgn[j][u] && S::v_poff(j, u) == T.v_poff[j][u] &&
+           S::v_soft(j, u) == T.v_soft[j][u] && S::v_mod(j, u) == T.v_mod[j][u] && S::v_first(j, u) == T.v_first[j][u] &&
+           S::v_val(j, u) == T.v_val[j][u];
+  ok = ok && S::off_r_body() == M.off_r_body && S::off_obst() == M.off_obst && S::off_lin() == M.off_lin &&
+       S::off_wu() == M.off_wu && S::off_goal() == M.off_goal && S::off_wgoal() == M.off_wgoal &&
+       S::off_wconstr() == M.off_wconstr && S::off_ws() == M.off_ws && S::has_goal() == M.has_goal &&
+       S::has_avoid() == M.has_avoid;
+  for (int j = 0; j < RMPC_MAX_JOINTS; j++) {
+    ok = ok && S::joint_type(j) == M.joint_type[j];
+    for (int c = 0; c < 3; c++)
+      ok = ok && S::joint_xyz(j, c) == M.joint_xyz[j][c] && S::joint_axis(j, c) == M.joint_axis[j][c] && S::dd_off(j, c) == M.dd_off[j][c];
+    for (int c = 0; c < 9; c++) ok = ok && S::joint_rot(j, c) == M.joint_rot[j][c];
+  }
+  return ok;
+}
+static int find_spec(const rmpc_desc &d, const DevModel &M, const DevTables &T) {
+#define RMPC_X(ID, S, R, NQ, NS) \
+  if (spec_matches<S>(d, M, T)) return ID;
+  RMPC_SPECS(RMPC_X)
+#undef RMPC_X
+  return -1;
+}
+static const char *spec_name(int id) {
+#define RMPC_X(ID, S, R, NQ, NS) \
+  if (id == ID) return #S;
+  RMPC_SPECS(RMPC_X)
+#undef RMPC_X
+  return "";
+}
+
 // ---- workspace carving ---------------------------------------------------------------
 struct Carver {
   char *base;
@@ -2767,12 +3051,12 @@ struct Phase {
   int B;
 };
 
-template <class C>
+template <class C, class V>
 static int launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hipStream_t st, int which) {
   const int B = ph.B;
   const int lanes = ph.W.Bp * h->M.N;
   if (ph.W.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
-  if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B, first,
+  if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C, V>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B, first,
                                            (first && h->warm_mode && h->have_duals) ? 1 : 0);
   else if (which == K_RICCATI) {
     if (C::IPB > 1 && B >= kGroupedMin)
@@ -2783,20 +3067,36 @@ static int launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hip
     const int tail_blocks = (C::IPB == 1 || B < kGroupedMin) ? B : kGroupedMin;
     hipLaunchKernelGGL((k_riccati<C, 1>), dim3(tail_blocks), dim3(64), 0, st, h->M, ph.W, B, first, pass);
   }
-  else hipLaunchKernelGGL((k_step<C>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B);
+  else hipLaunchKernelGGL((k_step<C, V>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B);
   return 0;
 }
 
+// Development builds may restrict the kernel variants that are instantiated (-DRMPC_DEV_VARIANTS=<bit mask over
+// variant_of()>: a full build takes minutes); the product build has them all.
+#ifndef RMPC_DEV_VARIANTS
+#define RMPC_DEV_VARIANTS 0x3f
+#endif
+template <int R, int NQ, int NS>
+constexpr bool variant_built() {
+  return (RMPC_DEV_VARIANTS >> ((R == RMPC_ROBOT_CHAIN ? (NQ == 3 ? 0 : 1) : 2) * 2 + (NS ? 1 : 0))) & 1;
+}
+
 static int launch_variant(rmpc_handle *h, const Phase &ph, int first, int pass, hipStream_t st, int which) {
-  switch (h->variant) {
-    case 0: return launch_pass<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>(h, ph, first, pass, st, which);
-    case 1: return launch_pass<Cfg<RMPC_ROBOT_CHAIN, 3, 1>>(h, ph, first, pass, st, which);
-    case 2: return launch_pass<Cfg<RMPC_ROBOT_CHAIN, 7, 0>>(h, ph, first, pass, st, which);
-    case 3: return launch_pass<Cfg<RMPC_ROBOT_CHAIN, 7, 1>>(h, ph, first, pass, st, which);
-    case 4: return launch_pass<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>(h, ph, first, pass, st, which);
-    case 5: return launch_pass<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>(h, ph, first, pass, st, which);
+  // a generated view when the descriptor's tables equal one (rmpc_create), the runtime tables otherwise
+#define RMPC_X(ID, S, R, NQ, NS)                                                            \
+  if constexpr (variant_built<R, NQ, NS>()) {                                               \
+    if (h->spec == ID) return launch_pass<Cfg<R, NQ, NS>, S>(h, ph, first, pass, st, which); \
   }
-  return fail("no kernel variant");
+  RMPC_SPECS(RMPC_X)
+#undef RMPC_X
+#define RMPC_V(ID, R, NQ, NS)                                                                         \
+  if constexpr (variant_built<R, NQ, NS>()) {                                                         \
+    if (h->variant == ID) return launch_pass<Cfg<R, NQ, NS>, RtView>(h, ph, first, pass, st, which);  \
+  }
+  RMPC_V(0, RMPC_ROBOT_CHAIN, 3, 0) RMPC_V(1, RMPC_ROBOT_CHAIN, 3, 1) RMPC_V(2, RMPC_ROBOT_CHAIN, 7, 0)
+  RMPC_V(3, RMPC_ROBOT_CHAIN, 7, 1) RMPC_V(4, RMPC_ROBOT_DIFFDRIVE, 3, 0) RMPC_V(5, RMPC_ROBOT_DIFFDRIVE, 3, 1)
+#undef RMPC_V
+  return fail("no kernel variant (built with RMPC_DEV_VARIANTS?)");
 }
 
 static hipEvent_t prof_event(rmpc_handle *h) {
@@ -2865,34 +3165,37 @@ static size_t carve_fused(const DevModel &M, int Bcap, void *base, FusedWs &F) {
   return (c.off + 255) & ~(size_t)255;
 }
 static bool fused_supported(int variant, const DevModel &M) {
-  // chain n = 3 and the diff-drive base, horizons that fit the 32 lanes of an instance
-  if (getenv("RMPC_FUSED_ARM")) return variant >= 0 && variant <= 5 && M.N <= kFusedStages;   // (experiment)
+  // chain n = 3 and the diff-drive base, horizons that fit the 32 lanes of an instance (the arm needs 2.5 KB of
+  // scratch per lane in the fused kernel and is 2.3x faster through the pass kernels: measured in round 2)
   return (variant == 0 || variant == 1 || variant == 4 || variant == 5) && M.N <= kFusedStages;
 }
 
-template <class C>
+template <class C, class V>
 static int launch_fused_t(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
                           double *d_zout, int *d_exit, int *d_iters, double *d_kkt, double *d_obj, hipStream_t st, int cap) {
   const int warm = (h->warm_mode && h->have_duals) ? 1 : 0;
   if (h->F.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
-  if (h->fused_ipw == 1)
-    hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, 1>), dim3(B), dim3(32), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
-                       d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm);
-  else
-    hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, 2>), dim3((B + 1) / 2), dim3(64), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
-                       d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm);
+  hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, V>), dim3((B + 1) / 2), dim3(64), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
+                     d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm);
   return 0;
 }
 static int launch_fused(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
                         double *d_zout, int *d_exit, int *d_iters, double *d_kkt, double *d_obj, hipStream_t st, int cap) {
-  switch (h->variant) {
-    case 0: return launch_fused_t<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
-    case 1: return launch_fused_t<Cfg<RMPC_ROBOT_CHAIN, 3, 1>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
-    case 2: return launch_fused_t<Cfg<RMPC_ROBOT_CHAIN, 7, 0>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
-    case 3: return launch_fused_t<Cfg<RMPC_ROBOT_CHAIN, 7, 1>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
-    case 4: return launch_fused_t<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
-    case 5: return launch_fused_t<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap);
+#define RMPC_X(ID, S, R, NQ, NS)                                                                                    \
+  if constexpr (Cfg<R, NQ, NS>::FUSED_OK && variant_built<R, NQ, NS>()) {                                           \
+    if (h->spec == ID)                                                                                              \
+      return launch_fused_t<Cfg<R, NQ, NS>, S>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap); \
   }
+  RMPC_SPECS(RMPC_X)
+#undef RMPC_X
+#define RMPC_V(ID, R, NQ, NS)                                                                                       \
+  if constexpr (variant_built<R, NQ, NS>()) {                                                                       \
+    if (h->variant == ID)                                                                                           \
+      return launch_fused_t<Cfg<R, NQ, NS>, RtView>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap); \
+  }
+  RMPC_V(0, RMPC_ROBOT_CHAIN, 3, 0) RMPC_V(1, RMPC_ROBOT_CHAIN, 3, 1)
+  RMPC_V(4, RMPC_ROBOT_DIFFDRIVE, 3, 0) RMPC_V(5, RMPC_ROBOT_DIFFDRIVE, 3, 1)
+#undef RMPC_V
   return fail("no fused kernel for this model");
 }
 
@@ -3019,6 +3322,26 @@ int rmpc_version(void) { return RMPC_VERSION; }
 #endif
 const char *rmpc_source_hash(void) { return RMPC_SOURCE_HASH; }
 const char *rmpc_last_error(void) { return g_err.c_str(); }
+/* generated views: source text for one descriptor, and which view a handle runs (see rmpc.h) */
+int64_t rmpc_spec_source(const rmpc_desc *desc, const char *name, char *out, int64_t cap) {
+  if (!desc || !name || desc->struct_size != (int)sizeof(rmpc_desc)) return fail("rmpc_spec_source: bad arguments");
+  DevModel M;
+  DevTables T;
+  std::string err;
+  if (build_model(*desc, M, err) != 0 || build_tables(*desc, M, T, err) != 0) return fail("invalid descriptor: " + err);
+  const std::string src = spec_source(*desc, M, T, name);
+  if (out && cap > (int64_t)src.size()) memcpy(out, src.c_str(), src.size() + 1);
+  return (int64_t)src.size() + 1;
+}
+const char *rmpc_spec_name(rmpc_handle *h) { return h ? spec_name(h->spec) : ""; }
+const char *rmpc_spec_for(const rmpc_desc *desc) {
+  if (!desc || desc->struct_size != (int)sizeof(rmpc_desc)) return "";
+  DevModel M;
+  DevTables T;
+  std::string err;
+  if (build_model(*desc, M, err) != 0 || build_tables(*desc, M, T, err) != 0) return "";
+  return spec_name(find_spec(*desc, M, T));
+}
 int rmpc_desc_size(void) { return (int)sizeof(rmpc_desc); }
 const char *rmpc_kernel_name(int idx) { return (idx >= 0 && idx < RMPC_NUM_KERNELS) ? kKernelNames[idx] : ""; }
 
@@ -3048,6 +3371,7 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   if (build_tables(*desc, h->M, h->T, err) != 0) { delete h; return fail("invalid descriptor: " + err); }
   h->variant = variant_of(*desc);
   if (h->variant < 0) { delete h; return fail("no kernel variant for this robot (supported: chain n=3, chain n=7, diff-drive n=3)"); }
+  h->spec = getenv("RMPC_NO_SPEC") ? -1 : find_spec(*desc, h->M, h->T);   // (debugging switch: runtime tables only)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { delete h; return fail("no HIP device available"); }
   if (desc->device < 0 || desc->device >= ndev) { delete h; return fail("device ordinal out of range"); }
@@ -3062,7 +3386,6 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   const size_t big = carve(h->M, h->Bp, h->max_passes, nullptr, tmp);
   const size_t small = h->Bpc ? carve(h->M, h->Bpc, 0, nullptr, tmp) : 0;
   h->fused = fused_supported(h->variant, h->M) && !getenv("RMPC_NO_FUSED");   // (debugging switch: pass kernels only)
-  if (const char *e = getenv("RMPC_FUSED_IPW")) h->fused_ipw = (atoi(e) == 1) ? 1 : 2;
   FusedWs ftmp;
   h->ws_bytes = big + small + (h->fused ? carve_fused(h->M, fused_columns(max_batch), nullptr, ftmp) : 0);
   e = hipMalloc(&h->ws_base, h->ws_bytes);

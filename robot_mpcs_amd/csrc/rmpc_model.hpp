@@ -84,6 +84,57 @@ struct DevTables {
   double v_val[RMPC_NV_MAX][kVarRows];               // constant bound value
 };
 
+// ---------------------------------------------------------------------------
+// Model views.  The device functions read the structure of the problem (row tables, parameter offsets, joint
+// chain) through a "view":
+//   * RtView  -- the runtime tables: any model the descriptor can express runs through it;
+//   * a generated view (rmpc_spec_gen.hpp, written by rmpc_spec_source from the descriptors of the shipped
+//     configurations) -- the same accessors as constexpr functions over literal tables.  After unrolling, the
+//     row loops of the sweep and the step phase are straight-line code: no table reads, no uniform branches
+//     around the requests, no masked rows, constant joint transforms.  This is the counterpart of the code
+//     the reference has FORCES Pro GENERATE for one problem (makeSolver.py / mpcModel.py:139-160 generateSolver);
+//     rmpc_create picks a generated view when its tables equal the descriptor's, the runtime view otherwise.
+// ---------------------------------------------------------------------------
+struct RtView {
+  static constexpr bool SPEC = false;
+  const DevModel &M;
+  const DevTables &T;
+  __device__ __forceinline__ RtView(const DevModel &m, const DevTables &t) : M(m), T(t) {}
+  __device__ __forceinline__ int nslots() const { return T.nslots; }
+  __device__ __forceinline__ int slot_fa(int s) const { return T.slot_fa[s]; }
+  __device__ __forceinline__ int slot_fb(int s) const { return T.slot_fb[s]; }
+  __device__ __forceinline__ int slot_row_begin(int s) const { return T.slot_row_begin[s]; }
+  __device__ __forceinline__ int nfkrows() const { return T.nfkrows; }
+  __device__ __forceinline__ int fk_row(int r) const { return T.fk_row[r]; }
+  __device__ __forceinline__ int fk_kind(int r) const { return T.fk_kind[r]; }
+  __device__ __forceinline__ int fk_obst(int r) const { return T.fk_obst[r]; }
+  __device__ __forceinline__ int fk_mod(int r) const { return T.fk_mod[r]; }
+  __device__ __forceinline__ int fk_first(int r) const { return T.fk_first[r]; }
+  __device__ __forceinline__ int fk_idx(int r) const { return T.fk_idx[r]; }
+  __device__ __forceinline__ int v_row(int j, int u) const { return T.v_row[j][u]; }
+  __device__ __forceinline__ int v_sgn(int j, int u) const { return T.v_sgn[j][u]; }
+  __device__ __forceinline__ int v_poff(int j, int u) const { return T.v_poff[j][u]; }
+  __device__ __forceinline__ int v_soft(int j, int u) const { return T.v_soft[j][u]; }
+  __device__ __forceinline__ int v_mod(int j, int u) const { return T.v_mod[j][u]; }
+  __device__ __forceinline__ int v_first(int j, int u) const { return T.v_first[j][u]; }
+  __device__ __forceinline__ double v_val(int j, int u) const { return T.v_val[j][u]; }
+  __device__ __forceinline__ int off_r_body() const { return M.off_r_body; }
+  __device__ __forceinline__ int off_obst() const { return M.off_obst; }
+  __device__ __forceinline__ int off_lin() const { return M.off_lin; }
+  __device__ __forceinline__ int off_wu() const { return M.off_wu; }
+  __device__ __forceinline__ int off_goal() const { return M.off_goal; }
+  __device__ __forceinline__ int off_wgoal() const { return M.off_wgoal; }
+  __device__ __forceinline__ int off_wconstr() const { return M.off_wconstr; }
+  __device__ __forceinline__ int off_ws() const { return M.off_ws; }
+  __device__ __forceinline__ int has_goal() const { return M.has_goal; }
+  __device__ __forceinline__ int has_avoid() const { return M.has_avoid; }
+  __device__ __forceinline__ int joint_type(int j) const { return M.joint_type[j]; }
+  __device__ __forceinline__ double joint_xyz(int j, int c) const { return M.joint_xyz[j][c]; }
+  __device__ __forceinline__ double joint_rot(int j, int c) const { return M.joint_rot[j][c]; }
+  __device__ __forceinline__ double joint_axis(int j, int c) const { return M.joint_axis[j][c]; }
+  __device__ __forceinline__ double dd_off(int f, int c) const { return M.dd_off[f][c]; }
+};
+
 struct Vec3 {
   double x, y, z;
 };
@@ -140,6 +191,7 @@ struct Cfg {
   // (point robot: 2 x 32 x 48 doubles = 24 KB per wavefront; the diff-drive records carry A5 | B5 and would
   // leave room for two wavefronts per CU only -- they go through the instance's block of the workspace)
   static constexpr bool FUSED_REC_LDS = (ROBOT_ == RMPC_ROBOT_CHAIN) && (NQ_ <= 3);
+  static constexpr bool FUSED_OK = !(ROBOT_ == RMPC_ROBOT_CHAIN && NQ_ > 3);   // models k_fused is built for
 };
 
 // ---------------------------------------------------------------------------
@@ -156,7 +208,8 @@ struct Kin {
   Vec3 pa[kMaxSlots], pb[kMaxSlots];  // positions of frame A / frame B of every slot
   double c, s, qx, qy;          // diff-drive base pose
 
-  __device__ __forceinline__ void compute(const DevModel &M, const DevTables &T, const double (&q)[C::NQ]) {
+  template <class V>
+  __device__ __forceinline__ void compute(const V &v, const double (&q)[C::NQ]) {
 #pragma unroll
     for (int sl = 0; sl < kMaxSlots; sl++) { pa[sl] = {0, 0, 0}; pb[sl] = {0, 0, 0}; }
     if constexpr (CHAIN) {
@@ -164,29 +217,34 @@ struct Kin {
       Vec3 o = {0, 0, 0};
 #pragma unroll
       for (int j = 0; j < C::NQ; j++) {
-        const double *t = M.joint_xyz[j];
+        const double t[3] = {v.joint_xyz(j, 0), v.joint_xyz(j, 1), v.joint_xyz(j, 2)};
         o.x += R[0] * t[0] + R[1] * t[1] + R[2] * t[2];
         o.y += R[3] * t[0] + R[4] * t[1] + R[5] * t[2];
         o.z += R[6] * t[0] + R[7] * t[1] + R[8] * t[2];
-        mul33(R, M.joint_rot[j]);
-        const double *ax = M.joint_axis[j];
+        {
+          double Rj[9];
+#pragma unroll
+          for (int c = 0; c < 9; c++) Rj[c] = v.joint_rot(j, c);
+          mul33(R, Rj);
+        }
+        const double ax[3] = {v.joint_axis(j, 0), v.joint_axis(j, 1), v.joint_axis(j, 2)};
         Vec3 a = {R[0] * ax[0] + R[1] * ax[1] + R[2] * ax[2], R[3] * ax[0] + R[4] * ax[1] + R[5] * ax[2],
                   R[6] * ax[0] + R[7] * ax[1] + R[8] * ax[2]};
         aj[j] = a;
         oj[j] = o;
-        if (M.joint_type[j] == RMPC_JOINT_REVOLUTE) {
+        if (v.joint_type(j) == RMPC_JOINT_REVOLUTE) {
           double Rq[9];
           rodrigues(ax, q[j], Rq);
           mul33(R, Rq);
-        } else if (M.joint_type[j] == RMPC_JOINT_PRISMATIC) {
+        } else if (v.joint_type(j) == RMPC_JOINT_PRISMATIC) {
           o.x += a.x * q[j];
           o.y += a.y * q[j];
           o.z += a.z * q[j];
         }
 #pragma unroll
         for (int sl = 0; sl < kMaxSlots; sl++) {
-          if (T.slot_fa[sl] == j) pa[sl] = o;
-          if (T.slot_fb[sl] == j) pb[sl] = o;
+          if (v.slot_fa(sl) == j) pa[sl] = o;
+          if (v.slot_fb(sl) == j) pb[sl] = o;
         }
       }
     } else {
@@ -195,11 +253,12 @@ struct Kin {
       qy = q[1];
 #pragma unroll
       for (int sl = 0; sl < kMaxSlots; sl++) {
-        if (sl < T.nslots) {
-          const double *o = M.dd_off[T.slot_fa[sl]];
+        if (sl < v.nslots()) {
+          const int fa = v.slot_fa(sl), fb = v.slot_fb(sl);
+          const double o[3] = {v.dd_off(fa, 0), v.dd_off(fa, 1), v.dd_off(fa, 2)};
           pa[sl] = {qx + c * o[0] - s * o[1], qy + s * o[0] + c * o[1], o[2]};
-          if (T.slot_fb[sl] >= 0) {
-            const double *ob = M.dd_off[T.slot_fb[sl]];
+          if (fb >= 0) {
+            const double ob[3] = {v.dd_off(fb, 0), v.dd_off(fb, 1), v.dd_off(fb, 2)};
             pb[sl] = {qx + c * ob[0] - s * ob[1], qy + s * ob[0] + c * ob[1], ob[2]};
           }
         }
@@ -208,33 +267,33 @@ struct Kin {
   }
 
   // Point of slot sl (static sl): P = pos(A) - pos(B) (B absent: pos(A)) and dP/dq.
-  template <int SL>
-  __device__ __forceinline__ Vec3 point(const DevModel &M, const DevTables &T, Vec3 (&J)[C::NQ]) const {
-    const int fa = T.slot_fa[SL], fb = T.slot_fb[SL];
+  template <int SL, class V>
+  __device__ __forceinline__ Vec3 point(const V &v, Vec3 (&J)[C::NQ]) const {
+    const int fa = v.slot_fa(SL), fb = v.slot_fb(SL);
     Vec3 P = pa[SL];
     if constexpr (CHAIN) {
 #pragma unroll
       for (int d = 0; d < C::NQ; d++) {
         Vec3 col = {0, 0, 0};
         if (d <= fa) {
-          if (M.joint_type[d] == RMPC_JOINT_REVOLUTE) col = cross(aj[d], pa[SL] - oj[d]);
-          else if (M.joint_type[d] == RMPC_JOINT_PRISMATIC) col = aj[d];
+          if (v.joint_type(d) == RMPC_JOINT_REVOLUTE) col = cross(aj[d], pa[SL] - oj[d]);
+          else if (v.joint_type(d) == RMPC_JOINT_PRISMATIC) col = aj[d];
         }
         if (fb >= 0 && d <= fb) {
           Vec3 cb = {0, 0, 0};
-          if (M.joint_type[d] == RMPC_JOINT_REVOLUTE) cb = cross(aj[d], pb[SL] - oj[d]);
-          else if (M.joint_type[d] == RMPC_JOINT_PRISMATIC) cb = aj[d];
+          if (v.joint_type(d) == RMPC_JOINT_REVOLUTE) cb = cross(aj[d], pb[SL] - oj[d]);
+          else if (v.joint_type(d) == RMPC_JOINT_PRISMATIC) cb = aj[d];
           col = col - cb;
         }
         J[d] = col;
       }
     } else {
-      const double *o = M.dd_off[fa];
+      const double o[3] = {v.dd_off(fa, 0), v.dd_off(fa, 1), v.dd_off(fa, 2)};
       J[0] = {1, 0, 0};
       J[1] = {0, 1, 0};
       J[2] = {-s * o[0] - c * o[1], c * o[0] - s * o[1], 0};
       if (fb >= 0) {
-        const double *ob = M.dd_off[fb];
+        const double ob[3] = {v.dd_off(fb, 0), v.dd_off(fb, 1), v.dd_off(fb, 2)};
         J[0] = {0, 0, 0};
         J[1] = {0, 0, 0};
         J[2] = {J[2].x - (-s * ob[0] - c * ob[1]), J[2].y - (c * ob[0] - s * ob[1]), 0};

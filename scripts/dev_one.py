@@ -1,9 +1,18 @@
+#!/usr/bin/env python3
+"""Development aid: solve one configuration a few times (fresh handle each time), print flag / iteration statistics."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from robot_mpcs_amd._lib import Solver
 from robot_mpcs_amd.scenarios import make_scenario
-sc = make_scenario("cfg2", B=8, seed=1)
-s = Solver(sc.desc, max_batch=8)
-r = s.solve(sc.xinit, sc.x0, sc.params)
-print(os.environ.get("RMPC_LIB_PATH", "default")[-22:], "fused" if not os.environ.get("RMPC_NO_FUSED") else "pass", r["iters"], r["exitflag"])
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 700
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+sc = make_scenario(name, B=B, seed=1)
+for r in range(reps):
+    s = Solver(sc.desc, max_batch=B)
+    g = s.solve(sc.xinit, sc.x0, sc.params)
+    print(name, B, "spec", repr(s.spec_name()), "iters mean %.4f" % g["iters"].mean(), "flags", np.unique(g["exitflag"], return_counts=True),
+          "zsum %.12e" % np.nansum(g["z"]), flush=True)
+    s.close()

@@ -16,11 +16,16 @@ sc = make_scenario(cfg, B=B, seed=1000)
 s = Solver(sc.desc, max_batch=B)
 s.solve(sc.xinit, sc.x0, sc.params)
 r = s.solve(sc.xinit, sc.x0, sc.params)
-st = s.fused_stamps((B + 1) // 2).astype(float)
+nb = (B + 1) // 2
+both = s.fused_stamps(2 * nb).astype(float)
+st, sec = both[:nb], both[nb:]
 tot = st[:, 4]
 print(f"{cfg} B={B}: blocks {len(st)}, passes mean {st[:, 5].mean():.1f} max {st[:, 5].max():.0f}")
 for i, name in enumerate(["sweep", "decide", "riccati", "step"]):
     print(f"  {name:8s} {st[:, i].sum() / tot.sum() * 100:5.1f} %   cycles per pass {st[:, i].sum() / st[:, 5].sum():9.0f}")
-print(f"  total cycles per pass {tot.sum() / st[:, 5].sum():.0f}   (memtime ticks at 100 MHz: x10 ns)")
+if sec[:, :4].sum() > 0:
+    for i, name in enumerate(["top loads + trial point", "objective, kinematics, distance rows", "single-variable rows", "dynamics, records, log"]):
+        print(f"     sweep / {name:38s} {sec[:, i].sum() / st[:, 5].sum():9.0f}")
+print(f"  total cycles per pass {tot.sum() / st[:, 5].sum():.0f}   (s_memtime: shader clock)")
 t0 = st[:, 6] - st[:, 6].min()
 print(f"  block start spread: median {np.median(t0):.0f} max {t0.max():.0f}; kernel span {(t0 + tot).max():.0f} ticks")
