@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--input-sets", type=int, default=6, help="distinct resident input sets the steps rotate through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline config only (no panda / boxer legs)")
+    ap.add_argument("--no-full-chip", action="store_true", help="skip the one-launch-fills-the-chip leg (profiles: keeps the kernel average to launches of one batch)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the exclusive per-kernel leg")
     ap.add_argument("--max-iter", type=int, default=25, help="cfg5 only: iteration cap of the real-time loop")
     ap.add_argument("--episode", type=int, default=40, help="cfg5 only: control steps per episode (then every instance restarts)")
@@ -207,6 +208,21 @@ def cpu_baseline(leg, gpu_z, gpu_exit, Solver, make_scenario, local_rank):
     from oracle.oracle import Oracle
     from robot_mpcs_amd.fleet import flags_consistent
     cores = os.cpu_count() or 1
+    # what this process may actually use: affinity mask and the cgroup CPU quota of the box (a GPU box hands a job a
+    # share of the host's cores; the scaling row cannot go beyond it)
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = cores
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    usable = int(max(1, min(affinity, quota if quota else affinity)))
     sc = leg.scs[(leg.counter - 1) % len(leg.scs)] if False else leg.scs[0]
     o = Oracle(leg.d)
     o.solve_batch(sc.xinit[:8], sc.x0[:8], sc.params[:8], nthreads=1)
@@ -215,7 +231,7 @@ def cpu_baseline(leg, gpu_z, gpu_exit, Solver, make_scenario, local_rank):
     per_solve_1t = (time.perf_counter() - t) / 24
     rows = []
     best = None
-    for nt in sorted({1, max(1, cores // 2), cores}):
+    for nt in sorted({1, max(1, usable // 2), usable, min(cores, 2 * usable)}):
         nb = int(min(leg.B, max(24, min(4096, 12.0 * nt / per_solve_1t))))     # about 12 s of CPU work per row
         o.solve_batch(sc.xinit[: min(nb, 4 * nt)], sc.x0[: min(nb, 4 * nt)], sc.params[: min(nb, 4 * nt)], nthreads=nt)
         t = time.perf_counter()
@@ -250,6 +266,7 @@ def cpu_baseline(leg, gpu_z, gpu_exit, Solver, make_scenario, local_rank):
         "sample": f"{nb} instances of the same workload (input set 0), one pass, OpenMP over instances; "
                   "the reference's own CPU path (FORCES Pro) cannot run here",
         "seconds": el, "thread_scaling": rows, "single_thread_ms_per_solve": 1e3 * per_solve_1t,
+        "host": {"cpus": cores, "affinity": affinity, "cgroup_cpu_quota": quota, "usable": usable},
         "exitflags_consistent_with_gpu": bool(flags_consistent(g["exitflag"], r["exitflag"], g["kkt"], 1e-6)),
         "max_abs_diff_vs_gpu_plan": dmax,
         "single_instance_cfg1": {"cpu_port_1_thread_ms": cpu1_ms, "hip_host_entry_ms": gpu1_ms,
@@ -373,11 +390,15 @@ def main():
     # RCCL all-gather of the solve statistics per rank (56 B): the only other collective
     allstats = fleet.gather_stats(fleet.solve_stats(exitflag, iters, kkt), dd, dev)
     latency_ms, excl_wall_ms, prof = (None, None, None)
+    n_excl = 0
     if not args.no_kernel_events:
-        latency_ms, excl_wall_ms, prof = leg.exclusive(8)
+        # whole rotations of the input sets, so that the exclusive average and the rocprofv3 average of a
+        # --streams 1 run (profiles/) cover the same mix of instances
+        n_excl = 2 * max(1, args.input_sets)
+        latency_ms, excl_wall_ms, prof = leg.exclusive(n_excl)
     passes = leg.solvers[0].last_passes()
     full_chip = None
-    if not args.no_kernel_events and cfg == "cfg2":
+    if not args.no_kernel_events and not args.no_full_chip and cfg == "cfg2":
         # the same kernel with the chip full from ONE launch: a batch of S x B instances on one stream (what the
         # S overlapped streams of the timed region add up to), exclusive HIP-event duration
         big = Leg(cfg, B * S, 1, 2, dev, 3000 + 101 * rank)
@@ -417,7 +438,7 @@ def main():
                            "streams_per_gpu": S, "input_sets": len(leg.scs)},
                    solve_stats=dict(stats, passes_last_step=passes))
         if prof:
-            rf = kernel_report(prof, excl_wall_ms, 8, B, d, stats["iters_mean"])
+            rf = kernel_report(prof, excl_wall_ms, n_excl, B, d, stats["iters_mean"])
             if rf:
                 io, ws, per_solve, fl = survey_bytes_per_solve(d, stats["iters_mean"])
                 rf["solve_level"] = {

@@ -393,11 +393,14 @@ struct SweepOrder {
   }
 };
 
+// The scalars of the model the sweep needs (everything else comes through the view)
+struct SweepK { int N; double dt; int use_curv; };
+
 // FIRSTC: 1 / 0 = the first pass of a solve (or not) known at compile time, -1 = taken from first_rt.  The rows
 // branch on it; callers that can afford two copies of the body (every kernel here) pass it as a constant so that
 // the rows of a stage form one basic block and their requests are issued together.
 template <class C, int EARLY_MODE = -1, class RP = gdouble, class V = RtView, int FIRSTC = -1>
-__device__ __forceinline__ void sweep_body(const DevModel &M, const V &v, const SweepIO<RP> &io, const int k,
+__device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const SweepIO<RP> &io, const int k,
                                            const bool first_rt, const bool nostep, const double alpha, const double adual,
                                            const double mu, Partials &out) {
   const bool first = FIRSTC < 0 ? first_rt : (FIRSTC != 0);
@@ -435,38 +438,17 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const V &v, const 
   const gdouble *__restrict__ lsrc = warm ? io.wl : lc;
   const unsigned loffl = warm ? loff1 : loff;
 #define IDXLL(slot) ((size_t)(slot) * SS + loffl)
+  double x1[NX], dx1[NX], n0[NX], n0n[NX], n1[NX], n1n[NX];
   {
     const size_t SSd = io.SSd;
     const unsigned loffd = io.loffd, loffd1 = io.loffd + (k < N - 1 ? io.kstrided : 0u);
 #pragma unroll
     for (int j = 0; j < NV; j++) { zo[j] = zc[IDXL(j)]; dzo[j] = dzp[(size_t)j * SSd + loffd]; }
-    double x1[NX], dx1[NX], n0[NX], n0n[NX], n1[NX], n1n[NX];
 #pragma unroll
     for (int j = 0; j < NX; j++) {
       x1[j] = zc[IDXL1(j)]; dx1[j] = dzp[(size_t)j * SSd + loffd1];
       n0[j] = nc[IDXL(j)];  n0n[j] = nup[(size_t)j * SSd + loffd];
       n1[j] = nc[IDXL1(j)]; n1n[j] = nup[(size_t)j * SSd + loffd1];
-    }
-#pragma unroll
-    for (int j = 0; j < NV; j++) {
-      z[j] = nostep ? zo[j] : zo[j] + alpha * dzo[j];
-      zn[IDXL(j)] = z[j];
-    }
-#pragma unroll
-    for (int j = 0; j < NX; j++) {
-      xk1[j] = nostep ? x1[j] : x1[j] + alpha * dx1[j];
-      double v = 0.0, w = 0.0;
-      if (!first && k >= 1) v = nostep ? n0[j] : n0[j] + alpha * (n0n[j] - n0[j]);
-      if (!first && k < N - 1) w = nostep ? n1[j] : n1[j] + alpha * (n1n[j] - n1[j]);
-      if (warm) {
-        // costates of the previous solve, shifted: nu_k <- nu_{k+1}, nu_{k+1} <- nu_{k+2} (last stage repeated)
-        const unsigned loff2 = loff1 + (k < N - 2 ? io.kstride : 0u);
-        if (k >= 1) v = io.wn[IDXL1(j)];
-        if (k < N - 1) w = io.wn[(size_t)j * SS + loff2];
-      }
-      nuk[j] = v;
-      nun[j] = w;
-      nn[IDXL(j)] = v;
     }
   }
   auto P = [&](int off) __attribute__((always_inline)) -> double { return pp[IDXL(off)]; };
@@ -512,6 +494,48 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const V &v, const 
     });
   }
 
+  struct VarBuf { double tcv[kVarRows], lcv[kVarRows], lim[kVarRows], wi[kVarRows]; };
+  auto var_load = [&](auto jc, VarBuf &Bv) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    // unconditional, clamped requests for the (up to) four rows of variable j
+#pragma unroll
+    for (int u = 0; u < kVarRows; u++) {
+      const int i = v.v_row(j, u);
+      const int ii = i >= 0 ? i : 0;
+      const int po = v.v_poff(j, u);
+      Bv.tcv[u] = tc[IDXL(ii)];
+      Bv.lcv[u] = lsrc[IDXLL(ii)];
+      const double pl = pp[IDXL(po >= 0 ? po : 0)];
+      Bv.lim[u] = po >= 0 ? pl : v.v_val(j, u);
+      Bv.wi[u] = 0.0;
+      if (i >= 0 && v.has_avoid() && v.v_first(j, u)) Bv.wi[u] = P(v.off_wconstr() + v.v_mod(j, u));
+    }
+  };
+  const double al = alpha, adl = adual;
+  // ---- trial point -----------------------------------------------------------------------------------
+  {
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      z[j] = nostep ? zo[j] : zo[j] + al * dzo[j];
+      zn[IDXL(j)] = z[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NX; j++) {
+      xk1[j] = nostep ? x1[j] : x1[j] + al * dx1[j];
+      double v = 0.0, w = 0.0;
+      if (!first && k >= 1) v = nostep ? n0[j] : n0[j] + al * (n0n[j] - n0[j]);
+      if (!first && k < N - 1) w = nostep ? n1[j] : n1[j] + al * (n1n[j] - n1[j]);
+      if (warm) {
+        // costates of the previous solve, shifted: nu_k <- nu_{k+1}, nu_{k+1} <- nu_{k+2} (last stage repeated)
+        const unsigned loff2 = loff1 + (k < N - 2 ? io.kstride : 0u);
+        if (k >= 1) v = io.wn[IDXL1(j)];
+        if (k < N - 1) w = io.wn[(size_t)j * SS + loff2];
+      }
+      nuk[j] = v;
+      nun[j] = w;
+      nn[IDXL(j)] = v;
+    }
+  }
   // ---- accumulators --------------------------------------------------------
   double gf[NV], q0[NV], q1[NV], rs[NV], Dg[NV], cs[NV];
   double Qqq[NQ][NQ];
@@ -567,8 +591,8 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const V &v, const 
       const double dlv = (mu - tcv * lcv - lcv * dtv) * frcp(tcv);
       // (null passes keep the point by selection, not by a zero step length: the step they would multiply
       //  may be stale -- after a failed factorisation of the fused kernel even non-finite)
-      tv = nostep ? tcv : tcv + alpha * dtv;
-      lv = nostep ? lcv : lcv + adual * dlv;
+      tv = nostep ? tcv : tcv + al * dtv;
+      lv = nostep ? lcv : lcv + adl * dlv;
     }
     tn[IDXL(i)] = tv;
     ln[IDXL(i)] = lv;
@@ -591,23 +615,6 @@ __device__ __forceinline__ void sweep_body(const DevModel &M, const V &v, const 
 
   // ---- single-variable rows: limits (general rows) and simple bounds, by variable ----
   // (generic lambda over a compile-time variable index: every array index stays a constant)
-  struct VarBuf { double tcv[kVarRows], lcv[kVarRows], lim[kVarRows], wi[kVarRows]; };
-  auto var_load = [&](auto jc, VarBuf &Bv) __attribute__((always_inline)) {
-    constexpr int j = decltype(jc)::value;
-    // unconditional, clamped requests for the (up to) four rows of variable j
-#pragma unroll
-    for (int u = 0; u < kVarRows; u++) {
-      const int i = v.v_row(j, u);
-      const int ii = i >= 0 ? i : 0;
-      const int po = v.v_poff(j, u);
-      Bv.tcv[u] = tc[IDXL(ii)];
-      Bv.lcv[u] = lsrc[IDXLL(ii)];
-      const double pl = pp[IDXL(po >= 0 ? po : 0)];
-      Bv.lim[u] = po >= 0 ? pl : v.v_val(j, u);
-      Bv.wi[u] = 0.0;
-      if (i >= 0 && v.has_avoid() && v.v_first(j, u)) Bv.wi[u] = P(v.off_wconstr() + v.v_mod(j, u));
-    }
-  };
   auto var_compute = [&](auto jc, const VarBuf &Bv) __attribute__((always_inline)) {
     constexpr int j = decltype(jc)::value;
 #pragma unroll
@@ -1024,8 +1031,9 @@ __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevMo
   }
   Partials pt;
   const V v(M, *Tp);
-  if (first) sweep_body<C, -1, gdouble, V, 1>(M, v, io, k, true, nostep, alpha, adual, W.mu[b], pt);
-  else sweep_body<C, -1, gdouble, V, 0>(M, v, io, k, false, nostep, alpha, adual, W.mu[b], pt);
+  const SweepK sk = {M.N, M.dt, M.use_curv};
+  if (first) sweep_body<C, -1, gdouble, V, 1>(sk, v, io, k, true, nostep, alpha, adual, W.mu[b], pt);
+  else sweep_body<C, -1, gdouble, V, 0>(sk, v, io, k, false, nostep, alpha, adual, W.mu[b], pt);
   const unsigned loff = io.loff;
   const size_t SS = io.SS;
   W.part[IDXL(P_F)] = pt.f;
@@ -2172,6 +2180,66 @@ __device__ RMPC_PHASE bool fused_recursion_mem(const int N, const double dt, con
   return riccati_recursion<C, kFusedStages, false, gdouble>(N, dt, mu, usec, lane, work, grec, kpb, kps, so);
 }
 
+// Bases of an instance's block in every array of the fused workspace.  They are recomputed from the instance index
+// where a phase needs them (a handful of integer operations) instead of living in registers across the phase calls.
+struct FusedPtrs {
+  gdouble *pz[2], *pt[2], *pl[2], *pn[2], *pg[2], *pj[2], *pp, *pdz, *pnn, *pgf, *pwl, *pwn;
+};
+__device__ __forceinline__ FusedPtrs fused_ptrs(const FusedWs &F, size_t b) {
+  asm volatile("" : "+v"(b));   // opaque: the bases must not be hoisted out of the pass loop (and spilled there)
+  const size_t S = kFusedStages;
+  FusedPtrs P;
+  P.pz[0] = (gdouble *)F.z[0] + b * F.nv * S; P.pz[1] = (gdouble *)F.z[1] + b * F.nv * S;
+  P.pt[0] = (gdouble *)F.t[0] + b * F.m * S; P.pt[1] = (gdouble *)F.t[1] + b * F.m * S;
+  P.pl[0] = (gdouble *)F.lam[0] + b * F.m * S; P.pl[1] = (gdouble *)F.lam[1] + b * F.m * S;
+  P.pn[0] = (gdouble *)F.nu[0] + b * F.nx * S; P.pn[1] = (gdouble *)F.nu[1] + b * F.nx * S;
+  P.pg[0] = (gdouble *)F.grow[0] + b * F.nhs * S; P.pg[1] = (gdouble *)F.grow[1] + b * F.nhs * S;
+  P.pj[0] = (gdouble *)F.Jq[0] + b * F.njqs * S; P.pj[1] = (gdouble *)F.Jq[1] + b * F.njqs * S;
+  P.pp = (gdouble *)F.p + b * F.npar * S;
+  P.pdz = (gdouble *)F.dz + b * F.nv * S;
+  P.pnn = (gdouble *)F.nunew + b * F.nx * S;
+  P.pgf = (gdouble *)F.gfa + b * F.nv * S;
+  P.pwl = (gdouble *)F.wlam + b * F.m * S;
+  P.pwn = (gdouble *)F.wnu + b * F.nx * S;
+  return P;
+}
+
+// (the sweep and the step phase are real functions for the generated views only: with the runtime tables they
+//  would need the model and the tables through memory instead of through the scalar registers of the kernel)
+template <class C, class RP, class V, int FIRSTC>
+__device__ __noinline__ void fused_sweep_call(const SweepK sk, const SweepIO<RP> io, const int k, const bool nostep,
+                                              const double alpha, const double adual, const double mu, Partials &out) {
+  const V v{};
+  sweep_body<C, -1, RP, V, FIRSTC>(sk, v, io, k, FIRSTC != 0, nostep, alpha, adual, mu, out);
+}
+template <class C, class RP, class V, int FIRSTC>
+__device__ __forceinline__ void fused_sweep(const SweepK sk, const V &v, const SweepIO<RP> &io, const int k, const bool nostep,
+                                            const double alpha, const double adual, const double mu, Partials &out) {
+#ifndef RMPC_NOINLINE_OFF
+  if constexpr (V::SPEC) {
+    fused_sweep_call<C, RP, V, FIRSTC>(sk, io, k, nostep, alpha, adual, mu, out);
+    return;
+  }
+#endif
+  sweep_body<C, -1, RP, V, FIRSTC>(sk, v, io, k, FIRSTC != 0, nostep, alpha, adual, mu, out);
+}
+template <class C, class RP, class V>
+__device__ __noinline__ void fused_step_call(const StepIO<RP> io, const int k, const double mu, double &ap, double &ad, double &gp) {
+  const V v{};
+  step_body<C, RP, V>(v, io, k, mu, ap, ad, gp);
+}
+template <class C, class RP, class V>
+__device__ __forceinline__ void fused_step(const V &v, const StepIO<RP> &io, const int k, const double mu, double &ap, double &ad,
+                                           double &gp) {
+#ifndef RMPC_NOINLINE_OFF
+  if constexpr (V::SPEC) {
+    fused_step_call<C, RP, V>(io, k, mu, ap, ad, gp);
+    return;
+  }
+#endif
+  step_body<C, RP, V>(v, io, k, mu, ap, ad, gp);
+}
+
 template <class C, bool REC_LDS, class V>
 __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTables *__restrict__ Tp, const FusedWs F, const int B,
                                               const double *__restrict__ xinit, const double *__restrict__ x0,
@@ -2200,29 +2268,19 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
   ldouble *const work = (ldouble *)lds + half * (LW + RECW);
   ldouble *const slots = work + LW;
 
-  // ---- per-instance bases of the workspace ----------------------------------------------------------
+  // ---- per-instance bases of the workspace: fused_ptrs(F, b) where a phase needs them ---------------------
   const size_t S = kFusedStages;
-  gdouble *const pz[2] = {(gdouble *)F.z[0] + b * F.nv * S, (gdouble *)F.z[1] + b * F.nv * S};
-  gdouble *const pt[2] = {(gdouble *)F.t[0] + b * F.m * S, (gdouble *)F.t[1] + b * F.m * S};
-  gdouble *const pl[2] = {(gdouble *)F.lam[0] + b * F.m * S, (gdouble *)F.lam[1] + b * F.m * S};
-  gdouble *const pn[2] = {(gdouble *)F.nu[0] + b * F.nx * S, (gdouble *)F.nu[1] + b * F.nx * S};
-  gdouble *const pg[2] = {(gdouble *)F.grow[0] + b * F.nhs * S, (gdouble *)F.grow[1] + b * F.nhs * S};
-  gdouble *const pj[2] = {(gdouble *)F.Jq[0] + b * F.njqs * S, (gdouble *)F.Jq[1] + b * F.njqs * S};
-  gdouble *const pp = (gdouble *)F.p + b * F.npar * S;
-  gdouble *const pdz = (gdouble *)F.dz + b * F.nv * S;
-  gdouble *const pnn = (gdouble *)F.nunew + b * F.nx * S;
-  gdouble *const pgf = (gdouble *)F.gfa + b * F.nv * S;
-  gdouble *const grec = (gdouble *)F.R + b * (size_t)N * C::RS;
-  gdouble *const kpb = (gdouble *)F.KP + b * (size_t)N * F.kps;
-
+  // the solver words of the two instances are parked here around the phase calls (the callees own the register file)
+  __shared__ Inst sinst[IPW];
   // ---- prologue: ABI rows of this stage -> the instance's block (x_1 := xinit, mpcModel.py:108) -------
+  const FusedPtrs P0 = fused_ptrs(F, b);
   if (valid && stage) {
     const double *zr = x0 + (b * N + k) * NV;
 #pragma unroll
     for (int j = 0; j < NV; j++) {
       double v = zr[j];
       if (k == 0 && j < NX) v = xinit[b * NX + j];
-      pz[0][j * S + k] = v;
+      P0.pz[0][j * S + k] = v;
     }
     if constexpr (REC_LDS) {   // the step slots are read (and discarded) by the first sweep: keep them finite
 #pragma unroll
@@ -2230,13 +2288,16 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
     }
     if (params) {
       const double *pr = params + (b * N + k) * M.npar;
-      for (int j = 0; j < M.npar; j++) pp[j * S + k] = pr[j];
+      for (int j = 0; j < M.npar; j++) P0.pp[j * S + k] = pr[j];
     }
   }
   Inst s;
-  gdouble *const pwl = (gdouble *)F.wlam + b * F.m * S;
-  gdouble *const pwn = (gdouble *)F.wnu + b * F.nx * S;
   const bool warm = warm_mode != 0;
+  // (every lane of an instance holds the same words: its lane 0 parks them, all lanes take them back)
+  auto park = [&]() __attribute__((always_inline)) { if (k == 0) sinst[half] = s; };
+  // (lane 0's store and the other lanes' loads are ordered by the wavefront fence: without it the compiler may
+  //  keep a lane's copy from the previous unpark -- nothing in that lane's own program wrote the words since)
+  auto unpark = [&]() __attribute__((always_inline)) { WSYNC(); s = sinst[half]; };
   inst_init(s, warm ? warm_mu(F.wmu[b], M.mu0) : M.mu0);
   if (!valid) s.status = 0;
   double gphi_sum = 0.0;   // merit slope of the current step (sum over the stages; step phase)
@@ -2262,35 +2323,38 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
 #ifdef RMPC_STAMPS
     q.tk[0] = q.tk[1] = q.tk[2] = q.tk[3] = 0;
 #endif
+    park();
     if (act && stage) {
       const int cur = s.cur, nxt = cur ^ 1;
       using RP = typename std::conditional<REC_LDS, ldouble, gdouble>::type;
+      const FusedPtrs Pw = fused_ptrs(F, b);
       SweepIO<RP> io;
-      io.zc = pz[cur]; io.tc = pt[cur]; io.lc = pl[cur]; io.nc = pn[cur];
-      io.zn = pz[nxt]; io.tn = pt[nxt]; io.ln = pl[nxt]; io.nn = pn[nxt];
-      io.pp = pp; io.gro = pg[cur]; io.jqo = pj[cur]; io.grn = pg[nxt]; io.jqn = pj[nxt];
-      io.gfa = pgf;
+      io.zc = Pw.pz[cur]; io.tc = Pw.pt[cur]; io.lc = Pw.pl[cur]; io.nc = Pw.pn[cur];
+      io.zn = Pw.pz[nxt]; io.tn = Pw.pt[nxt]; io.ln = Pw.pl[nxt]; io.nn = Pw.pn[nxt];
+      io.pp = Pw.pp; io.gro = Pw.pg[cur]; io.jqo = Pw.pj[cur]; io.grn = Pw.pg[nxt]; io.jqn = Pw.pj[nxt];
+      io.gfa = Pw.pgf;
       io.SS = S; io.loff = (unsigned)k; io.kstride = 1u;
       if constexpr (REC_LDS) {
         io.rec = slots + k * GS;
         io.dzp = slots + DZ_OFF; io.nup = slots + DZ_OFF + NV;
         io.SSd = 1; io.loffd = (unsigned)(k * GS); io.kstrided = (unsigned)GS;
       } else {
-        io.rec = grec + (size_t)k * C::RS;
-        io.dzp = pdz; io.nup = pnn;
+        io.rec = (gdouble *)F.R + (b * (size_t)N + k) * C::RS;
+        io.dzp = Pw.pdz; io.nup = Pw.pnn;
         io.SSd = S; io.loffd = (unsigned)k; io.kstrided = 1u;
       }
-      io.wl = pwl; io.wn = pwn; io.warm = warm ? 1 : 0;
-      constexpr int EM = -1;
+      io.wl = Pw.pwl; io.wn = Pw.pwn; io.warm = warm ? 1 : 0;
       const bool nostep = first || (s.redo != 0);
       double alpha = 0.0, adual = 0.0;
       if (!nostep) {
         alpha = ldexp(s.amin_p, -s.ls);
         adual = s.amin_d;
       }
-      if (first) sweep_body<C, EM, RP, V, 1>(M, v, io, k, true, nostep, alpha, adual, s.mu, q);
-      else sweep_body<C, EM, RP, V, 0>(M, v, io, k, false, nostep, alpha, adual, s.mu, q);
+      const SweepK sk = {M.N, M.dt, M.use_curv};
+      if (first) fused_sweep<C, RP, V, 1>(sk, v, io, k, nostep, alpha, adual, s.mu, q);
+      else fused_sweep<C, RP, V, 0>(sk, v, io, k, nostep, alpha, adual, s.mu, q);
     }
+    unpark();
     Reduced r;
     r.f = wave_sum<LPI>(q.f); r.th = wave_sum<LPI>(q.th); r.lgs = wave_sum<LPI>(q.logs); r.sumc = wave_sum<LPI>(q.sumc);
     r.badf = wave_sum<LPI>(q.bad);
@@ -2307,35 +2371,45 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
     bool recurse = false;
     if (act) recurse = inst_decide<C>(M, s, r, first, usec);
     STAMP_B(st_dec);
+    park();
+    const double mu_r = s.mu;
+    bool rec_ok = true;
     if (recurse) {
       bool ok;
       if constexpr (REC_LDS) {
         StepOut<ldouble> so;
         so.dz = slots + DZ_OFF; so.nunew = slots + DZ_OFF + NV; so.SS = 1; so.KS = GS;
-        ok = fused_recursion_lds<C>(M.N, M.dt, s.mu, usec, k, work, slots, so);
+        ok = fused_recursion_lds<C>(M.N, M.dt, mu_r, usec, k, work, slots, so);
       } else {
+        const FusedPtrs Pr = fused_ptrs(F, b);
         StepOut<gdouble> so;
-        so.dz = pdz; so.nunew = pnn; so.SS = S; so.KS = 1;
-        ok = fused_recursion_mem<C>(M.N, M.dt, s.mu, usec, k, work, grec, kpb, F.kps, so);
+        so.dz = Pr.pdz; so.nunew = Pr.pnn; so.SS = S; so.KS = 1;
+        ok = fused_recursion_mem<C>(M.N, M.dt, mu_r, usec, k, work, (gdouble *)F.R + b * (size_t)N * C::RS,
+                                    (gdouble *)F.KP + b * (size_t)N * F.kps, F.kps, so);
       }
-      inst_after_recursion(s, ok, usec);
+      rec_ok = ok;
     }
+    unpark();
+    if (recurse) inst_after_recursion(s, rec_ok, usec);
     GSYNC();   // dz, nunew
     STAMP_B(st_ric);
     // ---- step lengths of the new step -----------------------------------------------------------------
     const bool stepping = act && (s.status == ST_ACTIVE) && (s.newstep != 0);
     double ap = 1.0, ad = 1.0, gp = 0.0;
+    park();
     if (stepping && stage) {
       const int cur = s.cur;
       using RP = typename std::conditional<REC_LDS, ldouble, gdouble>::type;
+      const FusedPtrs Ps = fused_ptrs(F, b);
       StepIO<RP> io;
-      io.zc = pz[cur]; io.tc = pt[cur]; io.lc = pl[cur]; io.grow = pg[cur]; io.Jq = pj[cur];
-      io.gfa = pgf;
+      io.zc = Ps.pz[cur]; io.tc = Ps.pt[cur]; io.lc = Ps.pl[cur]; io.grow = Ps.pg[cur]; io.Jq = Ps.pj[cur];
+      io.gfa = Ps.pgf;
       io.SS = S; io.loff = (unsigned)k;
       if constexpr (REC_LDS) { io.dz = slots + DZ_OFF; io.SSd = 1; io.loffd = (unsigned)(k * GS); }
-      else { io.dz = pdz; io.SSd = S; io.loffd = (unsigned)k; }
-      step_body<C, RP, V>(v, io, k, s.mu, ap, ad, gp);
+      else { io.dz = Ps.pdz; io.SSd = S; io.loffd = (unsigned)k; }
+      fused_step<C, RP, V>(v, io, k, s.mu, ap, ad, gp);
     }
+    unpark();
     ap = wave_min<LPI>(ap); ad = wave_min<LPI>(ad); gp = wave_sum<LPI>(gp);
     if (stepping) {
       s.amin_p = fmin(s.amin_p, ap);
@@ -2357,17 +2431,18 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
 #endif
   // ---- epilogue: plan in the ABI layout, statistics ------------------------------------------------------
   GSYNC();
+  const FusedPtrs Pe = fused_ptrs(F, b);
   if (valid && stage) {
-    const gdouble *zf = pz[s.cur];
+    const gdouble *zf = Pe.pz[s.cur];
     double *zr = zout + (b * N + k) * NV;
 #pragma unroll
     for (int j = 0; j < NV; j++) zr[j] = zf[j * S + k];
     // multipliers for a warm start of the next solve of this instance (a failed solve leaves zeros and mu0)
     const bool okd = (s.status == ST_ACTIVE || s.status >= 0) && isfinite(s.mu) && s.mu > 0.0;
-    const gdouble *lf = pl[s.cur], *nf = pn[s.cur];
-    for (int i = 0; i < F.m; i++) pwl[i * S + k] = okd ? lf[i * S + k] : 0.0;
+    const gdouble *lf = Pe.pl[s.cur], *nf = Pe.pn[s.cur];
+    for (int i = 0; i < F.m; i++) Pe.pwl[i * S + k] = okd ? lf[i * S + k] : 0.0;
 #pragma unroll
-    for (int j = 0; j < NX; j++) pwn[j * S + k] = okd ? nf[j * S + k] : 0.0;
+    for (int j = 0; j < NX; j++) Pe.pwn[j * S + k] = okd ? nf[j * S + k] : 0.0;
   }
   if (valid && k == 0) {
     exitflag[b] = (s.status == ST_ACTIVE) ? 0 : s.status;
@@ -3371,7 +3446,11 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   if (build_tables(*desc, h->M, h->T, err) != 0) { delete h; return fail("invalid descriptor: " + err); }
   h->variant = variant_of(*desc);
   if (h->variant < 0) { delete h; return fail("no kernel variant for this robot (supported: chain n=3, chain n=7, diff-drive n=3)"); }
-  h->spec = getenv("RMPC_NO_SPEC") ? -1 : find_spec(*desc, h->M, h->T);   // (debugging switch: runtime tables only)
+  // Generated views are opt-in (RMPC_SPEC=1, read here once): measured in round 2 they change nothing for the point
+  // robot (1.58-1.61 M solves/s either way -- the fused kernel is bound by the traffic of the iterate, not by its
+  // instruction count) and cost the boxer 20 % (0.29 vs 0.37 M solves/s); DESIGN.md 5.1.
+  const char *use_spec = getenv("RMPC_SPEC");
+  h->spec = (use_spec && use_spec[0] && use_spec[0] != '0') ? find_spec(*desc, h->M, h->T) : -1;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { delete h; return fail("no HIP device available"); }
   if (desc->device < 0 || desc->device >= ndev) { delete h; return fail("device ordinal out of range"); }

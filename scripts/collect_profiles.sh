@@ -10,7 +10,7 @@ CFG=${2:-cfg2}
 B="--config $CFG --no-cpu-baseline --no-legs"
 rm -rf gpurun_out/prof_${TAG}_${CFG}*
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_${CFG}_s4 -- python3 bench.py $B --steps 24 --warmup 4 > gpurun_out/prof_${TAG}_${CFG}_s4.json 2> gpurun_out/prof_${TAG}_${CFG}_s4.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_${CFG}_s1 -- python3 bench.py $B --steps 12 --warmup 2 --streams 1 > gpurun_out/prof_${TAG}_${CFG}_s1.json 2> gpurun_out/prof_${TAG}_${CFG}_s1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_${CFG}_s1 -- python3 bench.py $B --steps 12 --warmup 2 --streams 1 --no-full-chip > gpurun_out/prof_${TAG}_${CFG}_s1.json 2> gpurun_out/prof_${TAG}_${CFG}_s1.err
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
