@@ -238,6 +238,10 @@ int64_t rmpc_spec_source(const rmpc_desc *desc, const char *name, char *out, int
 const char *rmpc_spec_name(rmpc_handle *h);
 const char *rmpc_spec_for(const rmpc_desc *desc);   /* the view rmpc_create would select (no GPU needed) */
 
+/* Test aid: overwrites the LDS of every CU of the handle's device with NaN patterns (tests/test_gpu_parity.py:
+ * a solve must not depend on what a previous kernel left in LDS). */
+int rmpc_debug_poison_lds(rmpc_handle *h);
+
 /* Development aid: per-block phase cycle counts of the last fused launch (8 words per block: sweep, decisions,
  * recursion, step, total, passes, start, -); all zero unless the library was built with -DRMPC_STAMPS. */
 int rmpc_debug_fused_stamps(rmpc_handle *h, long long *out, int nblocks);

@@ -71,7 +71,7 @@ class RmpcScene(C.Structure):
 EXPORTED_SYMBOLS = [
     "rmpc_version", "rmpc_source_hash", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
     "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_warm_start", "rmpc_set_profiling", "rmpc_get_profile",
-    "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep", "rmpc_spec_source", "rmpc_spec_name", "rmpc_spec_for",
+    "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep", "rmpc_spec_source", "rmpc_spec_name", "rmpc_spec_for", "rmpc_debug_poison_lds",
     "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_advance_device", "rmpc_advance_device_flags", "rmpc_free_space_device",
 ]
 
@@ -164,6 +164,8 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_spec_source.argtypes = [C.POINTER(RmpcDesc), C.c_char_p, C.c_char_p, C.c_int64]
     L.rmpc_spec_name.restype = C.c_char_p
     L.rmpc_spec_name.argtypes = [C.c_void_p]
+    L.rmpc_debug_poison_lds.restype = C.c_int
+    L.rmpc_debug_poison_lds.argtypes = [C.c_void_p]
     L.rmpc_spec_for.restype = C.c_char_p
     L.rmpc_spec_for.argtypes = [C.POINTER(RmpcDesc)]
     L.rmpc_debug_fused_stamps.restype = C.c_int
@@ -289,6 +291,10 @@ class Solver:
         if rc != 0:
             raise RmpcError("rmpc_create failed: " + self._L.rmpc_last_error().decode())
         self._h = h
+
+    def poison_lds(self):
+        """Test aid: NaN patterns into the LDS of every CU (``rmpc_debug_poison_lds``)."""
+        self._check(self._L.rmpc_debug_poison_lds(self._h), "rmpc_debug_poison_lds")
 
     def spec_name(self) -> str:
         """Name of the generated view this handle runs ("" = runtime row tables); ``rmpc_spec_name``."""

@@ -3688,6 +3688,25 @@ int rmpc_debug_fused_stamps(rmpc_handle *h, long long *out, int nblocks) {
   return 0;
 }
 
+/* test aid: fills the LDS of every CU with NaN patterns (a kernel that owns all 160 KB of a CU's LDS, four
+ * blocks per CU worth of launches), so that a test can show that no kernel depends on what it finds there */
+__global__ __launch_bounds__(64) void k_poison_lds(double *sink) {
+  extern __shared__ double pl[];
+  const int n = 64 * 1024 / 8;
+  for (int i = threadIdx.x; i < n; i += 64) pl[i] = __longlong_as_double(0x7ff8dead0000beefLL);
+  __syncthreads();
+  if (sink && threadIdx.x == 0 && blockIdx.x == 0) sink[0] = pl[n - 1];
+}
+int rmpc_debug_poison_lds(rmpc_handle *h) {
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipFuncSetAttribute((const void *)k_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  for (int rep = 0; rep < 4; rep++) hipLaunchKernelGGL(k_poison_lds, dim3(4096), dim3(64), 64 * 1024, h->stream, (double *)nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x0, const double *params,
                      double *out_Q, double *out_q0, double *out_q1, double *out_rc, double *out_g, double *out_f) {
   if (!h) return fail("null handle");

@@ -63,6 +63,22 @@ def test_solve_matches_oracle(rt, name, B, seed):
     np.testing.assert_allclose(gpu["obj"], cpu["obj"], rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("name,B", [("cfg1", 3), ("cfg2", 2048), ("cfg3", 512)])
+def test_solve_does_not_depend_on_stale_lds(rt, name, B):
+    """The fused kernel keeps its stage records in LDS; every entry the recursion reads must have been written by the
+    sweep of the same pass.  (Round 2: the defect entries of the last stage were not -- 0 * NaN reached the gains on a
+    box whose previous kernel had left NaN patterns there.)  The LDS of every CU is filled with NaNs before the solve."""
+    sc = rt["make_scenario"](name, B=B, seed=21)
+    s = rt["Solver"](sc.desc, max_batch=B)
+    clean = s.solve(sc.xinit, sc.x0, sc.params)
+    s.poison_lds()
+    dirty = s.solve(sc.xinit, sc.x0, sc.params)
+    s.close()
+    assert np.array_equal(clean["exitflag"], dirty["exitflag"]) and np.array_equal(clean["iters"], dirty["iters"])
+    assert np.array_equal(clean["z"], dirty["z"])
+    assert np.isin(clean["exitflag"], (1, 2)).mean() > 0.95
+
+
 @pytest.mark.parametrize("name,B,seed", [("cfg2", 2048, 7), ("cfg3", 1280, 8)])
 def test_survivor_migration_is_transparent(rt, name, B, seed):
     """Batches of >= 1024 instances move their last survivors to the compact workspace
