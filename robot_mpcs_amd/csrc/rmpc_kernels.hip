@@ -1317,7 +1317,7 @@ struct FusedSlots {
   static constexpr int GS = (NEED + 7) / 8 * 8;   // 64-byte slots: the sweep stores its record with aligned 16-byte writes
 };
 
-template <class C, int LPI, bool SLOTS = false, class RP = gdouble>
+template <class C, int LPI, bool SLOTS = false, class RP = gdouble, bool OWNER = false>
 __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, const double mu, const bool usec, const int lane,
                                                   ldouble *const img, const RP *const rb, gdouble *const kpb,
                                                   const int kps, const StepOut<RP> so, ldouble *const slots = nullptr) {
@@ -1580,8 +1580,229 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       recv[u] = rb[(size_t)k * sstr + (e < C::RS ? e : 0)];
     }
   };
-  if constexpr (!FAST) fetch_stage(N - 1);
-  for (int k = FAST ? -1 : N - 1; k >= 0; k--) {
+  // ---- fused kernel, diff-drive: backward pass with the structure of [A | B] used ------------------------------
+  // [A | B] of the unicycle is the identity outside the reduced block (x, y, theta, v, omega) = x[{0,1,2,6,7}] and its
+  // two input columns: T = P [A|B] has 7 computed columns (the identity columns are columns of P, the slack column
+  // is zero) and Q += [A|B]^T T has 7 computed rows, each a 5-term sum -- a third of the dense products, with the
+  // terms in the dense order (zeros and ones drop out exactly), so the values are those of the generic path.  The
+  // record entries a lane needs come straight from the record into its registers one stage ahead (no staging copy of
+  // the record in LDS), every producer stores its part of the gain image to the gain record itself (no read-back),
+  // and a stage has four ordering points instead of five.
+  constexpr bool DDFAST = DD && OWNER && !SLOTS;
+  if constexpr (DDFAST) {
+    constexpr int NR = 5, NT = NR + 2;            // reduced states; computed columns of T (reduced + inputs)
+    constexpr int OFF_KFF = NW * NX, OFF_PT = NW * NX + NW, OFF_P = OFF_PT + NP2, OFF_RC = OFF_P + NX;
+    ldouble *const sA5 = sAB, *const sB5 = sAB + 25, *const sZ = sAB + 35;   // sZ: one zero word
+    ldouble *const sT7 = sT;                                                   // T[l][jc], 8 x 7
+    auto Rl = [](int r) __attribute__((always_inline)) { return r < 3 ? r : r + 3; };        // reduced index -> state
+    auto rid = [](int j) __attribute__((always_inline)) { return j < 3 ? j : (j >= 6 && j < 8 ? j - 3 : -1); };
+    // phase A: entries of T this lane forms
+    constexpr int TA = (NX * NT + LPI - 1) / LPI;
+    int tpo[TA], tco[TA], tcs[TA], tst[TA];
+    bool tok[TA];
+#pragma unroll
+    for (int u = 0; u < TA; u++) {
+      const int t = lane + LPI * u;
+      tok[u] = t < NX * NT;
+      const int tc = tok[u] ? t : 0;
+      const int i = tc / NT, jc = tc - i * NT;
+      tpo[u] = i * NX;                                   // row i of P
+      tco[u] = jc < NR ? jc : 25 + (jc - NR);            // M[rl][jc]: A5[rl][jc] | B5[rl][jc - 5]   (offset in sAB)
+      tcs[u] = jc < NR ? NR : 2;
+      tst[u] = tc;
+    }
+    // phase B: the lane's entries of the stage Hessian and its gradient entry
+    int bto[EPL], bts[EPL], bco[EPL], bcs[EPL], bio[EPL];
+    bool bok[EPL], bI[EPL];
+    auto colsrc = [&](int j, int &to, int &ts) __attribute__((always_inline)) {
+      // T[l][j] for l = 0..7: computed column | column of P | zero
+      if (j < NX) {
+        if (rid(j) >= 0) { to = (int)(sT7 - img) + rid(j); ts = NT; }
+        else { to = (int)(sP - img) + j; ts = NX; }
+      } else if (j >= NX + NS) { to = (int)(sT7 - img) + NR + (j - NX - NS); ts = NT; }
+      else { to = (int)(sZ - img); ts = 0; }
+    };
+    auto rowsrc = [&](int i, int &co, int &cs, bool &isI) __attribute__((always_inline)) {
+      // [A|B][l][i] for l in the reduced rows: column of A5 | column of B5 | nothing
+      isI = false;
+      if (i < NX) {
+        if (rid(i) >= 0) { co = (int)(sA5 - img) + rid(i); cs = NR; }
+        else { co = (int)(sZ - img); cs = 0; isI = true; }
+      } else if (i >= NX + NS) { co = (int)(sB5 - img) + (i - NX - NS); cs = 2; }
+      else { co = (int)(sZ - img); cs = 0; }
+    };
+#pragma unroll
+    for (int u = 0; u < EPL; u++) {
+      const int e = lane + LPI * u;
+      bok[u] = e < NV * NV;
+      const int ec = bok[u] ? e : 0;
+      const int i = ec / NV, j = ec - i * NV;
+      colsrc(j, bto[u], bts[u]);
+      rowsrc(i, bco[u], bcs[u], bI[u]);
+      bio[u] = bto[u] + (i < NX ? i : 0) * bts[u];      // T[i][j] (identity rows)
+    }
+    const int lq = lane < NV ? lane : 0;
+    int qco, qcs;
+    bool qI;
+    rowsrc(lq, qco, qcs, qI);
+    const int lr = lane < NX ? lane : 0;
+    // record entries of the stage about to be processed, one stage ahead
+    double rq[EPL], q0n = 0, q1n = 0, rcn = 0, abn[2] = {0, 0};
+    auto fetch_dd = [&](int k) __attribute__((always_inline)) {
+      const RP *const r = rb + (size_t)k * sstr;
+#pragma unroll
+      for (int u = 0; u < EPL; u++) rq[u] = r[qp[u]];
+      q0n = r[C::R_Q0 + lq]; q1n = r[C::R_Q1 + lq]; rcn = r[C::R_RC + lr];
+#pragma unroll
+      for (int u = 0; u < 2; u++) abn[u] = r[C::R_A5 + (lane + LPI * u < 35 ? lane + LPI * u : 0)];
+    };
+    // cost-to-go entries of this lane (as in the generic path)
+    constexpr int PPL2 = (NX * NX + NX + LPI - 1) / LPI;
+    if (lane == 0) sZ[0] = 0.0;
+    fetch_dd(N - 1);
+    for (int k = N - 1; k >= 0; k--) {
+      gdouble *const kpk = kpb + (size_t)k * kps;
+      // this stage's record entries are in registers; the next one's leave now
+      double rqc[EPL];
+#pragma unroll
+      for (int u = 0; u < EPL; u++) rqc[u] = rq[u];
+      const double q0c = q0n, q1c = q1n, rcc = rcn;
+      // ([A5 | B5] and rc of THIS stage are in LDS since the last phase of the previous stage)
+      if (k > 0) fetch_dd(k - 1);
+      const bool rec_cost = k < N - 1;
+      WSYNC();   // P, p of stage k+1 and [A5 | B5], rc of this stage are in LDS
+      if (rec_cost) {
+        // ---- phase A: T = P [A|B] (computed columns), Pc = P rc + p ------------------------------------------
+        double tv[TA];
+#pragma unroll
+        for (int u = 0; u < TA; u++) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int r = 0; r < NR; r++) sacc += sP[tpo[u] + Rl(r)] * sAB[tco[u] + r * tcs[u]];
+          tv[u] = sacc;
+        }
+        double pcv = 0.0;
+        if (lane < NX) {
+          pcv = sp[lane];
+#pragma unroll
+          for (int l = 0; l < NX; l++) pcv += sP[lane * NX + l] * src[l];
+        }
+#pragma unroll
+        for (int u = 0; u < TA; u++)
+          if (tok[u]) sT7[tst[u]] = tv[u];
+        if (lane < NX) sPc[lane] = pcv;
+        WSYNC();
+      }
+      // ---- phase B: Q = record + [A|B]^T T, q = q0 - mu q1 + [A|B]^T Pc ----------------------------------------
+      {
+        double qv[EPL];
+#pragma unroll
+        for (int u = 0; u < EPL; u++) {
+          double v = rqc[u];   // (the diff-drive model carries no curvature block: cwt * 0)
+          if (rec_cost) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) v += img[bco[u] + r * bcs[u]] * img[bto[u] + Rl(r) * bts[u]];
+            v += bI[u] ? img[bio[u]] : 0.0;
+          }
+          qv[u] = v;
+        }
+        double gq = q0c - mu * q1c;
+        if (rec_cost) {
+#pragma unroll
+          for (int r = 0; r < NR; r++) gq += img[qco + r * qcs] * sPc[Rl(r)];
+          gq += qI ? sPc[lq < NX ? lq : 0] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < EPL; u++)
+          if (bok[u]) sQ[lane + LPI * u] = qv[u];
+        if (lane < NV) sq[lane] = gq;
+        if (lane < NX) kpk[OFF_RC + lane] = rcc;   // the stage's defect: part of its gain image
+      }
+      WSYNC();
+      // ---- phase C: Cholesky of Qww (every lane, registers) and the gains (one column per lane) ----------------
+      {
+        double L[NW][NW], invd[NW];
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+          double dg = sQ[(NX + j) * NV + NX + j];
+#pragma unroll
+          for (int l = 0; l < j; l++) dg -= L[j][l] * L[j][l];
+          if (!(dg > 0.0)) chol_ok = false;
+          double inv = __builtin_amdgcn_rsq(dg);
+          inv = inv * (1.5 - 0.5 * dg * inv * inv);
+          inv = inv * (1.5 - 0.5 * dg * inv * inv);
+          L[j][j] = dg * inv;
+          invd[j] = inv;
+#pragma unroll
+          for (int i = j + 1; i < NW; i++) {
+            double sacc = sQ[(NX + i) * NV + NX + j];
+#pragma unroll
+            for (int l = 0; l < j; l++) sacc -= L[i][l] * L[j][l];
+            L[i][j] = sacc * inv;
+          }
+        }
+        if (lane <= NX) {
+          double col[NW];
+#pragma unroll
+          for (int i = 0; i < NW; i++) col[i] = (lane < NX) ? -sQ[(NX + i) * NV + lane] : -sq[NX + i];
+          chol_solve<NW>(L, invd, col);
+#pragma unroll
+          for (int i = 0; i < NW; i++) {
+            const int o = lane < NX ? i * NX + lane : OFF_KFF + i;
+            img[o] = col[i];
+            kpk[o] = col[i];
+          }
+        }
+      }
+      WSYNC();
+      // ---- phase D: cost-to-go P = sym(Qxx + Qxw K), p = qx + Qxw kff; [A5 | B5], rc of the next stage to LDS -----
+      {
+        double pn[PPL2];
+#pragma unroll
+        for (int u = 0; u < PPL2; u++) {
+          const int e = lane + LPI * u;
+          pn[u] = 0.0;
+          if (e < NX * NX + NX) {
+            const bool isP = e < NX * NX;
+            const int i = isP ? e / NX : e - NX * NX, j = isP ? e - i * NX : 0;
+            const ldouble *const a0 = isP ? sQ + i * NV + j : sq + i;
+            const ldouble *const c0 = isP ? sQ + j * NV + i : sq + i;
+            const ldouble *const cq = isP ? sQ + j * NV + NX : sQ + i * NV + NX;
+            double a = *a0, c = *c0;
+#pragma unroll
+            for (int l = 0; l < NW; l++) {
+              a += sQ[i * NV + NX + l] * (isP ? sK[l * NX + j] : skf[l]);
+              c += cq[l] * (isP ? sK[l * NX + i] : skf[l]);
+            }
+            pn[u] = 0.5 * (a + c);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < PPL2; u++) {
+          const int e = lane + LPI * u;
+          if (e < NX * NX) {
+            sP[e] = pn[u];
+            const int i = e / NX, j = e - i * NX;
+            if (i <= j) { sPt[tri(i, j)] = pn[u]; kpk[OFF_PT + tri(i, j)] = pn[u]; }
+          } else if (e < NX * NX + NX) {
+            sp[e - NX * NX] = pn[u];
+            kpk[OFF_P + (e - NX * NX)] = pn[u];
+          }
+        }
+        if (k > 0) {
+          // (what fetch_dd(k - 1) brought: nobody reads sAB / src again before the ordering point at the loop top)
+#pragma unroll
+          for (int u = 0; u < 2; u++)
+            if (lane + LPI * u < 35) sAB[lane + LPI * u] = abn[u];
+          if (lane < NX) src[lane] = rcn;
+        } else if (lane < NX) {
+          src[lane] = rcc;   // (single-stage horizon: the forward pass reads the defect of stage 0 from the image)
+        }
+      }
+    }
+  }
+  if constexpr (!FAST && !DDFAST) fetch_stage(N - 1);
+  for (int k = (FAST || DDFAST) ? -1 : N - 1; k >= 0; k--) {
     // -- the image of stage k+1 is complete: it leaves for the gain record (read now, stored after the
     //    barrier); the stage record goes to LDS, the request for the next one leaves ----------------
     double kpv[KPL];
@@ -1835,6 +2056,91 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
         sx += dxme;
         sx += (isq ? h : 0.0) * dxv;
         sx += (isq ? h2 : h) * dw;
+        dxn[lane] = sx;
+      }
+    }
+    return true;
+  }
+  // ---- fused kernel, diff-drive: forward rollout with ONE ordering point per stage ---------------------------------
+  // As in the chain's path, the lane that forms an entry of dx+ computes the two input steps it needs itself (same
+  // expression, same value as the lane that stores them); dx ping-pongs between two buffers; the image and [A5 | B5]
+  // of the next stage travel from the gain record / the stage record while this stage is computed; the products
+  // with [A | B] keep only its non-trivial entries, in the dense order.
+  if constexpr (DDFAST) {
+    constexpr int NR = 5;
+    constexpr int OFF_KFF = NW * NX, OFF_PT = NW * NX + NW, OFF_P = OFF_PT + NP2, OFF_RC = OFF_P + NX;
+    ldouble *const sA5 = sAB, *const sB5 = sAB + 25, *const sZ = sAB + 35;
+    ldouble *const dx0 = sdx, *const dx1 = sPc;
+    auto Rl = [](int r) __attribute__((always_inline)) { return r < 3 ? r : r + 3; };
+    auto rid = [](int j) __attribute__((always_inline)) { return j < 3 ? j : (j >= 6 && j < 8 ? j - 3 : -1); };
+    double fv[KPL], abf[2] = {0, 0};
+    auto fetch_f = [&](int k) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < KPL; u++) {
+        const int e = lane + LPI * u;
+        fv[u] = kpb[(size_t)k * kps + (e < KPW ? e : 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) abf[u] = rb[(size_t)k * sstr + C::R_A5 + (lane + LPI * u < 35 ? lane + LPI * u : 0)];
+    };
+    WSYNC();
+    if (lane < NX) dx0[lane] = 0.0;
+    if (N > 1) fetch_f(1);
+    // role of the lane in the "offset + row . dx" stream: an input / slack step (lanes < NW) or a costate
+    const bool isw = lane < NW, isn = lane >= NW && lane < NW + NX;
+    const int in = isn ? lane - NW : 0;
+    int ro[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) ro[j] = isw ? lane * NX + j : OFF_PT + tri(in, j);
+    const int oo = isw ? OFF_KFF + lane : OFF_P + in;
+    // dx+ entry of the lane
+    const int lx = lane < NX ? lane : 0;
+    const bool xI = rid(lx) < 0;
+    const int ao = xI ? 35 : rid(lx) * NR, as = xI ? 0 : 1;   // row of A5 (offsets in sAB; 35 = the zero word)
+    const int bo = xI ? 35 : 25 + rid(lx) * 2, bs = xI ? 0 : 1;
+    for (int k = 0; k < N; k++) {
+      const ldouble *const dxc = (k & 1) ? dx1 : dx0;
+      ldouble *const dxn = (k & 1) ? dx0 : dx1;
+      if (k > 0) {
+        // image and [A5 | B5] of this stage (what the previous iteration requested)
+#pragma unroll
+        for (int u = 0; u < KPL; u++) {
+          const int e = lane + LPI * u;
+          if (e < KPW) img[e] = fv[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+          if (lane + LPI * u < 35) sAB[lane + LPI * u] = abf[u];
+      }
+      if (k + 1 < N) fetch_f(k + 1);
+      WSYNC();
+      double dx[NX];
+#pragma unroll
+      for (int j = 0; j < NX; j++) dx[j] = dxc[j];
+      // own entry of the step / costate
+      double sown = img[oo];
+#pragma unroll
+      for (int j = 0; j < NX; j++) sown += img[ro[j]] * dx[j];
+      // the two input steps (every lane: the dx+ lanes need them)
+      double du[2];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        double sacc = img[OFF_KFF + NS + c];
+#pragma unroll
+        for (int j = 0; j < NX; j++) sacc += img[(NS + c) * NX + j] * dx[j];
+        du[c] = sacc;
+      }
+      const double rcv = img[OFF_RC + lx];
+      const double dxo = dxc[in], dxme = dxc[lx];
+      if (lane < NW + NX) so.dz[(size_t)(isw ? NX + lane : in) * so.SS + (size_t)k * so.KS] = isw ? sown : dxo;
+      if (isn && k >= 1) so.nunew[(size_t)in * so.SS + (size_t)k * so.KS] = sown;
+      if (k < N - 1 && lane < NX) {
+        double sx = rcv;
+#pragma unroll
+        for (int r = 0; r < NR; r++) sx += sAB[ao + r * as] * dx[Rl(r)];
+        sx += xI ? dxme : 0.0;
+#pragma unroll
+        for (int c = 0; c < 2; c++) sx += sAB[bo + c * bs] * du[c];
         dxn[lane] = sx;
       }
     }
@@ -2177,7 +2483,7 @@ template <class C>
 __device__ RMPC_PHASE bool fused_recursion_mem(const int N, const double dt, const double mu, const bool usec, const int lane,
                                                ldouble *const work, const gdouble *const grec, gdouble *const kpb,
                                                const int kps, const StepOut<gdouble> so) {
-  return riccati_recursion<C, kFusedStages, false, gdouble>(N, dt, mu, usec, lane, work, grec, kpb, kps, so);
+  return riccati_recursion<C, kFusedStages, false, gdouble, true>(N, dt, mu, usec, lane, work, grec, kpb, kps, so);
 }
 
 // Bases of an instance's block in every array of the fused workspace.  They are recomputed from the instance index
