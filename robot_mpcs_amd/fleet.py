@@ -134,7 +134,7 @@ class MixedFleetShard:
                 z=torch.empty((B, N, nv), dtype=torch.float64, device=device),
                 ef=torch.empty(B, dtype=torch.int32, device=device), it=torch.empty(B, dtype=torch.int32, device=device),
                 kkt=torch.empty(B, dtype=torch.float64, device=device), obj=torch.empty(B, dtype=torch.float64, device=device),
-                stream=torch.cuda.Stream(device=device)))
+                stream=torch.cuda.Stream(device=device)))   # (a higher dispatch priority for the arm's stream: no effect, measured)
         torch.cuda.synchronize(device)
 
     @property
