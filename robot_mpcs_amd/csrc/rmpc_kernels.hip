@@ -3546,8 +3546,12 @@ static size_t carve_fused(const DevModel &M, int Bcap, void *base, FusedWs &F) {
   return (c.off + 255) & ~(size_t)255;
 }
 static bool fused_supported(int variant, const DevModel &M) {
-  // chain n = 3 and the diff-drive base, horizons that fit the 32 lanes of an instance (the arm needs 2.5 KB of
-  // scratch per lane in the fused kernel and is 2.3x faster through the pass kernels: measured in round 2)
+  // chain n = 3 and the diff-drive base, horizons that fit the 32 lanes of an instance.  The arm stays with the pass
+  // kernels: in the fused kernel (measured twice in round 2, the second time with the recursion as a real function) a
+  // pass takes 670 k cycles -- its recursion on the 32 lanes of an instance alone 347 k, twice the 64-lane pass kernel
+  // -- against ~480 k for the four pass kernels.  Restructuring the arm's recursion like the chain's (records straight
+  // into registers, three ordering points per stage) changed nothing either (6.8 vs 7.0 ms per batch): it is bound by
+  // the 7 x 7 factorisation and the cost-to-go update, not by its ordering points.
   return (variant == 0 || variant == 1 || variant == 4 || variant == 5) && M.N <= kFusedStages;
 }
 
