@@ -999,7 +999,9 @@ __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevMo
                                                const int B, const int first, const int warm) {
   const int gid = blockIdx.x * kSweepBlock + threadIdx.x;
   const int li = gid % W.Bp;   // position in the compacted list of iterating instances
-  const int k = gid / W.Bp;    // uniform per wavefront (Bp % 64 == 0)
+  // (Bp % 64 == 0: the stage is the same for the 64 lanes of a wavefront; as a scalar, every test on it is a scalar
+  //  branch taken by the whole wavefront instead of a masked region)
+  const int k = __builtin_amdgcn_readfirstlane(gid / W.Bp);
   if (li >= *W.n_act || k >= M.N) return;
   const int b = W.act_idx[li];
   if (W.status[b] != ST_ACTIVE) return;
@@ -2404,7 +2406,7 @@ __global__ __launch_bounds__(kSweepBlock) void k_step(const DevModel M, const De
                                               const int B) {
   const int gid = blockIdx.x * kSweepBlock + threadIdx.x;
   const int li = gid % W.Bp;
-  const int k = gid / W.Bp;
+  const int k = __builtin_amdgcn_readfirstlane(gid / W.Bp);   // (uniform per wavefront, see k_sweep)
   if (li >= *W.n_act || k >= M.N) return;
   const int b = W.act_idx[li];
   if (W.status[b] != ST_ACTIVE || !W.newstep[b]) return;
