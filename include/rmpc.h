@@ -228,7 +228,7 @@ int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x
 /* Generated solvers.  The reference has FORCES Pro generate C code for ONE problem (mpcModel.py:139-160
  * generateSolver, examples/makeSolver.py); here the kernels exist in two forms: over runtime row tables (any
  * descriptor) and over "generated views" -- the same tables as compile-time constants, so that the row loops of
- * the hot kernels become straight-line code (csrc/rmpc_spec_gen.hpp, one view per shipped configuration).
+ * the hot kernels become straight-line code (csrc/rmpc_spec_gen.hpp: views of the point-robot configurations).
  * rmpc_spec_source writes the C++ text of the view of `desc` (struct `name`) into out (cap bytes incl. the
  * terminating 0) and returns the size it needs, or -1; scripts/gen_specs.py assembles the header from it.
  * With RMPC_SPEC=1 in the environment rmpc_create selects a view when every table entry equals the descriptor's

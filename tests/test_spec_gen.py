@@ -30,8 +30,8 @@ def test_shipped_configs_resolve_to_a_view():
              ("cfg1", "cfg2", "cfg3", "cfg4", "pointRobot", "boxer", "panda", "wc_point", "wc_boxer", "wc_panda")}
     assert names["cfg2"] == "SpecPointRobot"
     assert names["cfg1"] == names["pointRobot"] == "SpecPointRobotExample"
-    assert names["cfg3"] == "SpecBoxer" and names["boxer"] == "SpecBoxerYaml"
-    # the arm and other structures (another module list, another obstacle count) run over the runtime tables
+    # the boxer, the arm and other structures (another module list, another obstacle count) run over the runtime tables
+    assert names["cfg3"] == names["boxer"] == ""
     assert names["cfg4"] == names["panda"] == names["wc_panda"] == ""
     assert names["wc_point"] == names["wc_boxer"] == ""
     # the horizon, the weights and the solver options are not part of a view
@@ -39,7 +39,7 @@ def test_shipped_configs_resolve_to_a_view():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,B", [("cfg1", 8), ("cfg2", 512), ("cfg3", 256), ("boxer", 64)])
+@pytest.mark.parametrize("cfg,B", [("cfg1", 8), ("cfg2", 512), ("pointRobot", 16)])
 def test_view_equals_runtime_tables(cfg, B, monkeypatch):
     from robot_mpcs_amd._lib import Solver
     from robot_mpcs_amd.scenarios import make_scenario
