@@ -231,9 +231,10 @@ int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x
  * the hot kernels become straight-line code (csrc/rmpc_spec_gen.hpp: views of the point-robot configurations).
  * rmpc_spec_source writes the C++ text of the view of `desc` (struct `name`) into out (cap bytes incl. the
  * terminating 0) and returns the size it needs, or -1; scripts/gen_specs.py assembles the header from it.
- * With RMPC_SPEC=1 in the environment rmpc_create selects a view when every table entry equals the descriptor's
- * (opt-in: measured equal to the runtime tables on the point robot and slower on the boxer);
- * rmpc_spec_name returns its name ("" = runtime tables). */
+ * rmpc_create selects a view when every table entry equals the descriptor's (RMPC_NO_SPEC=1 in the environment
+ * forces the runtime tables; measured: same throughput, one batch alone 6 % faster on the point robot, 20 % slower
+ * on the boxer, whose views are therefore not generated: DESIGN.md 5.1); rmpc_spec_name returns the view's name
+ * ("" = runtime tables). */
 int64_t rmpc_spec_source(const rmpc_desc *desc, const char *name, char *out, int64_t cap);
 const char *rmpc_spec_name(rmpc_handle *h);
 const char *rmpc_spec_for(const rmpc_desc *desc);   /* the view rmpc_create would select (no GPU needed) */

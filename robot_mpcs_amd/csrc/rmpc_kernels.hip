@@ -3758,11 +3758,11 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   if (build_tables(*desc, h->M, h->T, err) != 0) { delete h; return fail("invalid descriptor: " + err); }
   h->variant = variant_of(*desc);
   if (h->variant < 0) { delete h; return fail("no kernel variant for this robot (supported: chain n=3, chain n=7, diff-drive n=3)"); }
-  // Generated views are opt-in (RMPC_SPEC=1, read here once): measured in round 2 they change nothing for the point
-  // robot (1.58-1.61 M solves/s either way -- the fused kernel is bound by the traffic of the iterate, not by its
-  // instruction count) and cost the boxer 20 % (0.29 vs 0.37 M solves/s); DESIGN.md 5.1.
-  const char *use_spec = getenv("RMPC_SPEC");
-  h->spec = (use_spec && use_spec[0] && use_spec[0] != '0') ? find_spec(*desc, h->M, h->T) : -1;
+  // Generated views (rmpc_spec_gen.hpp: the point-robot configurations).  Measured in round 2: with the chip full the
+  // throughput is the same as with the runtime tables (1.60-1.65 M solves/s either way: the fused kernel is bound by
+  // the traffic of the iterate, not by its instruction count), one batch alone is 6 % faster (4.42 vs 4.69 ms: the
+  // requests of the sweep leave ahead of the arithmetic).  RMPC_NO_SPEC=1 (read here once) forces the runtime tables.
+  h->spec = getenv("RMPC_NO_SPEC") ? -1 : find_spec(*desc, h->M, h->T);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { delete h; return fail("no HIP device available"); }
   if (desc->device < 0 || desc->device >= ndev) { delete h; return fail("device ordinal out of range"); }

@@ -1,6 +1,6 @@
 """Generated model views (csrc/rmpc_spec_gen.hpp): the committed header is what the generator writes from the
 library's own table builder, the shipped configurations resolve to a view, test configurations to the runtime
-tables; on the GPU a view (opt-in, RMPC_SPEC=1) and the runtime tables give the same plans."""
+tables; on the GPU a view and the runtime tables (RMPC_NO_SPEC=1) give the same plans."""
 import importlib.util
 import os
 
@@ -45,12 +45,12 @@ def test_view_equals_runtime_tables(cfg, B, monkeypatch):
     from robot_mpcs_amd.scenarios import make_scenario
 
     sc = make_scenario(cfg, B=B, seed=77)
-    monkeypatch.setenv("RMPC_SPEC", "1")     # (opt-in, read once at rmpc_create)
+    monkeypatch.delenv("RMPC_NO_SPEC", raising=False)
     a = Solver(sc.desc, max_batch=B)
     assert a.spec_name() != ""
     ra = a.solve(sc.xinit, sc.x0, sc.params)
     a.close()
-    monkeypatch.delenv("RMPC_SPEC")
+    monkeypatch.setenv("RMPC_NO_SPEC", "1")     # (read once, at rmpc_create)
     b = Solver(sc.desc, max_batch=B)
     assert b.spec_name() == ""
     rb = b.solve(sc.xinit, sc.x0, sc.params)
