@@ -2512,40 +2512,64 @@ __device__ __forceinline__ FusedPtrs fused_ptrs(const FusedWs &F, size_t b) {
   return P;
 }
 
-// (the sweep and the step phase are real functions for the generated views only: with the runtime tables they
-//  would need the model and the tables through memory instead of through the scalar registers of the kernel)
-template <class C, class RP, class V, int FIRSTC>
-__device__ __noinline__ void fused_sweep_call(const SweepK sk, const SweepIO<RP> io, const int k, const bool nostep,
-                                              const double alpha, const double adual, const double mu, Partials &out) {
-  const V v{};
-  sweep_body<C, -1, RP, V, FIRSTC>(sk, v, io, k, FIRSTC != 0, nostep, alpha, adual, mu, out);
-}
-template <class C, class RP, class V, int FIRSTC>
-__device__ __forceinline__ void fused_sweep(const SweepK sk, const V &v, const SweepIO<RP> &io, const int k, const bool nostep,
-                                            const double alpha, const double adual, const double mu, Partials &out) {
-#ifndef RMPC_NOINLINE_OFF
-  if constexpr (V::SPEC) {
-    fused_sweep_call<C, RP, V, FIRSTC>(sk, io, k, nostep, alpha, adual, mu, out);
-    return;
+// The sweep and the step phase are real functions for the generated views only: with the runtime tables they would
+// need the model and the tables through memory instead of through the scalar registers of the kernel.  A call takes
+// a handful of scalars -- the callee derives the instance's bases from the pointer block in device memory (scalar
+// loads) -- and returns its results by value: with the SweepIO / StepIO structs as arguments and the partials behind
+// a reference, the argument and result traffic through scratch was 1.4 KB per lane and pass, more than the 0.9 KB
+// the sweep stores by design (round 2, L2 counters: 60 % of the fabric traffic of a launch were writes).
+struct StepRes { double ap, ad, gp; };
+template <class C, class V, int FIRSTC, bool REC_LDS>
+__device__ __noinline__ Partials fused_sweep_call(const FusedWs *Fp, const int N, const double dt, const int use_curv,
+                                                  const size_t b, const int cur, const int k, ldouble *const slots,
+                                                  const bool nostep, const double alpha, const double adual, const double mu,
+                                                  const int warm) {
+  using RP = typename std::conditional<REC_LDS, ldouble, gdouble>::type;
+  constexpr int GS = FusedSlots<C>::GS, DZ_OFF = FusedSlots<C>::DZ_OFF, NV = C::NV;
+  const FusedWs &F = *Fp;
+  const size_t S = kFusedStages;
+  const int nxt = cur ^ 1;
+  const FusedPtrs Pw = fused_ptrs(F, b);
+  SweepIO<RP> io;
+  io.zc = Pw.pz[cur]; io.tc = Pw.pt[cur]; io.lc = Pw.pl[cur]; io.nc = Pw.pn[cur];
+  io.zn = Pw.pz[nxt]; io.tn = Pw.pt[nxt]; io.ln = Pw.pl[nxt]; io.nn = Pw.pn[nxt];
+  io.pp = Pw.pp; io.gro = Pw.pg[cur]; io.jqo = Pw.pj[cur]; io.grn = Pw.pg[nxt]; io.jqn = Pw.pj[nxt];
+  io.gfa = Pw.pgf;
+  io.SS = S; io.loff = (unsigned)k; io.kstride = 1u;
+  if constexpr (REC_LDS) {
+    io.rec = slots + k * GS;
+    io.dzp = slots + DZ_OFF; io.nup = slots + DZ_OFF + NV;
+    io.SSd = 1; io.loffd = (unsigned)(k * GS); io.kstrided = (unsigned)GS;
+  } else {
+    io.rec = (gdouble *)F.R + (b * (size_t)N + k) * C::RS;
+    io.dzp = Pw.pdz; io.nup = Pw.pnn;
+    io.SSd = S; io.loffd = (unsigned)k; io.kstrided = 1u;
   }
-#endif
-  sweep_body<C, -1, RP, V, FIRSTC>(sk, v, io, k, FIRSTC != 0, nostep, alpha, adual, mu, out);
-}
-template <class C, class RP, class V>
-__device__ __noinline__ void fused_step_call(const StepIO<RP> io, const int k, const double mu, double &ap, double &ad, double &gp) {
+  io.wl = Pw.pwl; io.wn = Pw.pwn; io.warm = warm;
+  const SweepK sk = {N, dt, use_curv};
   const V v{};
-  step_body<C, RP, V>(v, io, k, mu, ap, ad, gp);
+  Partials q = {0, 0, 0, 0, 0, 0, 0, 0, 1e300, 0};
+  sweep_body<C, -1, RP, V, FIRSTC>(sk, v, io, k, FIRSTC != 0, nostep, alpha, adual, mu, q);
+  return q;
 }
-template <class C, class RP, class V>
-__device__ __forceinline__ void fused_step(const V &v, const StepIO<RP> &io, const int k, const double mu, double &ap, double &ad,
-                                           double &gp) {
-#ifndef RMPC_NOINLINE_OFF
-  if constexpr (V::SPEC) {
-    fused_step_call<C, RP, V>(io, k, mu, ap, ad, gp);
-    return;
-  }
-#endif
-  step_body<C, RP, V>(v, io, k, mu, ap, ad, gp);
+template <class C, class V, bool REC_LDS>
+__device__ __noinline__ StepRes fused_step_call(const FusedWs *Fp, const size_t b, const int cur, const int k,
+                                                ldouble *const slots, const double mu) {
+  using RP = typename std::conditional<REC_LDS, ldouble, gdouble>::type;
+  constexpr int GS = FusedSlots<C>::GS, DZ_OFF = FusedSlots<C>::DZ_OFF;
+  const FusedWs &F = *Fp;
+  const size_t S = kFusedStages;
+  const FusedPtrs Ps = fused_ptrs(F, b);
+  StepIO<RP> io;
+  io.zc = Ps.pz[cur]; io.tc = Ps.pt[cur]; io.lc = Ps.pl[cur]; io.grow = Ps.pg[cur]; io.Jq = Ps.pj[cur];
+  io.gfa = Ps.pgf;
+  io.SS = S; io.loff = (unsigned)k;
+  if constexpr (REC_LDS) { io.dz = slots + DZ_OFF; io.SSd = 1; io.loffd = (unsigned)(k * GS); }
+  else { io.dz = Ps.pdz; io.SSd = S; io.loffd = (unsigned)k; }
+  const V v{};
+  StepRes r = {1.0, 1.0, 0.0};
+  step_body<C, RP, V>(v, io, k, mu, r.ap, r.ad, r.gp);
+  return r;
 }
 
 template <class C, bool REC_LDS, class V>
@@ -2632,7 +2656,20 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
     q.tk[0] = q.tk[1] = q.tk[2] = q.tk[3] = 0;
 #endif
     park();
-    if (act && stage) {
+    if constexpr (V::SPEC) {
+      // generated view: the sweep is a call (scalars in, partials out)
+      if (act && stage) {
+        const bool nostep = first || (s.redo != 0);
+        double alpha = 0.0, adual = 0.0;
+        if (!nostep) {
+          alpha = ldexp(s.amin_p, -s.ls);
+          adual = s.amin_d;
+        }
+        const FusedWs *const Fp = (const FusedWs *)(Tp + 1);   // (the pointer block behind the row tables)
+        if (first) q = fused_sweep_call<C, V, 1, REC_LDS>(Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, nostep, alpha, adual, s.mu, warm ? 1 : 0);
+        else q = fused_sweep_call<C, V, 0, REC_LDS>(Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, nostep, alpha, adual, s.mu, warm ? 1 : 0);
+      }
+    } else if (act && stage) {
       const int cur = s.cur, nxt = cur ^ 1;
       using RP = typename std::conditional<REC_LDS, ldouble, gdouble>::type;
       const FusedPtrs Pw = fused_ptrs(F, b);
@@ -2659,8 +2696,8 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
         adual = s.amin_d;
       }
       const SweepK sk = {M.N, M.dt, M.use_curv};
-      if (first) fused_sweep<C, RP, V, 1>(sk, v, io, k, nostep, alpha, adual, s.mu, q);
-      else fused_sweep<C, RP, V, 0>(sk, v, io, k, nostep, alpha, adual, s.mu, q);
+      if (first) sweep_body<C, -1, RP, V, 1>(sk, v, io, k, true, nostep, alpha, adual, s.mu, q);
+      else sweep_body<C, -1, RP, V, 0>(sk, v, io, k, false, nostep, alpha, adual, s.mu, q);
     }
     unpark();
     Reduced r;
@@ -2705,7 +2742,13 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
     const bool stepping = act && (s.status == ST_ACTIVE) && (s.newstep != 0);
     double ap = 1.0, ad = 1.0, gp = 0.0;
     park();
-    if (stepping && stage) {
+    if constexpr (V::SPEC) {
+      if (stepping && stage) {
+        const FusedWs *const Fp = (const FusedWs *)(Tp + 1);
+        const StepRes sr = fused_step_call<C, V, REC_LDS>(Fp, b, s.cur, k, slots, s.mu);
+        ap = sr.ap; ad = sr.ad; gp = sr.gp;
+      }
+    } else if (stepping && stage) {
       const int cur = s.cur;
       using RP = typename std::conditional<REC_LDS, ldouble, gdouble>::type;
       const FusedPtrs Ps = fused_ptrs(F, b);
@@ -2715,7 +2758,7 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
       io.SS = S; io.loff = (unsigned)k;
       if constexpr (REC_LDS) { io.dz = slots + DZ_OFF; io.SSd = 1; io.loffd = (unsigned)(k * GS); }
       else { io.dz = Ps.pdz; io.SSd = S; io.loffd = (unsigned)k; }
-      fused_step<C, RP, V>(v, io, k, s.mu, ap, ad, gp);
+      step_body<C, RP, V>(v, io, k, s.mu, ap, ad, gp);
     }
     unpark();
     ap = wave_min<LPI>(ap); ad = wave_min<LPI>(ad); gp = wave_sum<LPI>(gp);
@@ -3792,8 +3835,11 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
     h->Wc.active_hist = h->W.active_hist;  // one history per batch, whichever workspace the pass ran in
   }
   if (h->fused) carve_fused(h->M, fused_columns(max_batch), (char *)h->ws_base + big + small, h->F);
-  e = hipMalloc((void **)&h->d_T, sizeof(DevTables));
+  // (the row tables, and behind them a copy of the fused workspace's pointer block: the phase functions of the
+  //  fused kernel take the instance's bases from there instead of receiving two dozen pointers per call)
+  e = hipMalloc((void **)&h->d_T, sizeof(DevTables) + sizeof(FusedWs));
   if (e == hipSuccess) e = hipMemcpy(h->d_T, &h->T, sizeof(DevTables), hipMemcpyHostToDevice);
+  if (e == hipSuccess && h->fused) e = hipMemcpy((void *)(h->d_T + 1), &h->F, sizeof(FusedWs), hipMemcpyHostToDevice);
   if (e != hipSuccess) { (void)hipFree(h->ws_base); delete h; return fail(std::string("row tables: ") + hipGetErrorString(e)); }
   e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_active, sizeof(int), hipHostMallocDefault);
