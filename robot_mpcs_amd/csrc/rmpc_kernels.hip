@@ -2572,6 +2572,35 @@ __device__ __noinline__ StepRes fused_step_call(const FusedWs *Fp, const size_t 
   return r;
 }
 
+// Generated views, records in LDS: the recursion and the step lengths of the new step in ONE call (the step phase reads
+// what the forward pass has just left in the slots; a call less per pass and no register saves around it).
+// (Inlined into the pass loop instead, with only the sweep as a call, the kernel is twice as slow: measured.)
+struct RecStep { int ok; double ap, ad, gp; };
+template <class C, class V>
+__device__ __noinline__ RecStep fused_recursion_step(const FusedWs *Fp, const int N, const double dt, const double mu,
+                                                     const bool usec, const size_t b, const int cur, const int k,
+                                                     ldouble *const work, ldouble *const slots) {
+  constexpr int GS = FusedSlots<C>::GS, DZ_OFF = FusedSlots<C>::DZ_OFF, NV = C::NV;
+  StepOut<ldouble> so;
+  so.dz = slots + DZ_OFF; so.nunew = slots + DZ_OFF + NV; so.SS = 1; so.KS = GS;
+  const bool ok = riccati_recursion<C, kFusedStages, true, ldouble>(N, dt, mu, usec, k, work, slots, nullptr, 0, so, slots);
+  RecStep r = {ok ? 1 : 0, 1.0, 1.0, 0.0};
+  GSYNC();   // dz of every stage is in the slots
+  if (ok && k < N) {
+    const FusedWs &F = *Fp;
+    const size_t S = kFusedStages;
+    const FusedPtrs Ps = fused_ptrs(F, b);
+    StepIO<ldouble> io;
+    io.zc = Ps.pz[cur]; io.tc = Ps.pt[cur]; io.lc = Ps.pl[cur]; io.grow = Ps.pg[cur]; io.Jq = Ps.pj[cur];
+    io.gfa = Ps.pgf;
+    io.SS = S; io.loff = (unsigned)k;
+    io.dz = slots + DZ_OFF; io.SSd = 1; io.loffd = (unsigned)(k * GS);
+    const V v{};
+    step_body<C, ldouble, V>(v, io, k, mu, r.ap, r.ad, r.gp);
+  }
+  return r;
+}
+
 template <class C, bool REC_LDS, class V>
 __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTables *__restrict__ Tp, const FusedWs F, const int B,
                                               const double *__restrict__ xinit, const double *__restrict__ x0,
@@ -2719,7 +2748,16 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
     park();
     const double mu_r = s.mu;
     bool rec_ok = true;
-    if (recurse) {
+    constexpr bool RSTEP = V::SPEC && REC_LDS;   // recursion and step lengths in one call
+    double ap = 1.0, ad = 1.0, gp = 0.0;
+    if constexpr (RSTEP) {
+      if (recurse) {
+        const FusedWs *const Fp = (const FusedWs *)(Tp + 1);
+        const RecStep rs = fused_recursion_step<C, V>(Fp, M.N, M.dt, mu_r, usec, b, s.cur, k, work, slots);
+        rec_ok = rs.ok != 0;
+        ap = rs.ap; ad = rs.ad; gp = rs.gp;
+      }
+    } else if (recurse) {
       bool ok;
       if constexpr (REC_LDS) {
         StepOut<ldouble> so;
@@ -2740,9 +2778,10 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
     STAMP_B(st_ric);
     // ---- step lengths of the new step -----------------------------------------------------------------
     const bool stepping = act && (s.status == ST_ACTIVE) && (s.newstep != 0);
-    double ap = 1.0, ad = 1.0, gp = 0.0;
     park();
-    if constexpr (V::SPEC) {
+    if constexpr (RSTEP) {
+      // (done with the recursion)
+    } else if constexpr (V::SPEC) {
       if (stepping && stage) {
         const FusedWs *const Fp = (const FusedWs *)(Tp + 1);
         const StepRes sr = fused_step_call<C, V, REC_LDS>(Fp, b, s.cur, k, slots, s.mu);
