@@ -2572,31 +2572,54 @@ __device__ __noinline__ StepRes fused_step_call(const FusedWs *Fp, const size_t 
   return r;
 }
 
-// Generated views, records in LDS: the recursion and the step lengths of the new step in ONE call (the step phase reads
-// what the forward pass has just left in the slots; a call less per pass and no register saves around it).
-// (Inlined into the pass loop instead, with only the sweep as a call, the kernel is twice as slow: measured.)
-struct RecStep { int ok; double ap, ad, gp; };
-template <class C, class V>
-__device__ __noinline__ RecStep fused_recursion_step(const FusedWs *Fp, const int N, const double dt, const double mu,
-                                                     const bool usec, const size_t b, const int cur, const int k,
-                                                     ldouble *const work, ldouble *const slots) {
+// Generated views, records in LDS: the step lengths of a fresh step are formed at the beginning of the sweep call
+// instead of after the recursion -- the whole wavefront calls (the reductions over the 32
+// lanes of the instance run inside), lanes without work skip the bodies.  The slacks and multipliers the step phase
+// reads are then read again by the sweep a few thousand cycles later (L2) instead of a whole recursion later (fabric),
+// and a pass is two calls: this one and the recursion (1.90-1.94 -> 1.97-2.03 M solves/s, same results).
+struct SweepStepRes { Partials q; double amin_p, amin_d, gphi; };
+template <class C, class V, int FIRSTC>
+__device__ __noinline__ SweepStepRes fused_sweep_step_call(const FusedWs *Fp, const int N, const double dt, const int use_curv,
+                                                           const size_t b, const int cur, const int k, ldouble *const slots,
+                                                           const bool live, const bool nostep, const bool fresh, const int ls,
+                                                           const double amin_p_in, const double amin_d_in, const double gphi_in,
+                                                           const double mu, const int warm) {
   constexpr int GS = FusedSlots<C>::GS, DZ_OFF = FusedSlots<C>::DZ_OFF, NV = C::NV;
-  StepOut<ldouble> so;
-  so.dz = slots + DZ_OFF; so.nunew = slots + DZ_OFF + NV; so.SS = 1; so.KS = GS;
-  const bool ok = riccati_recursion<C, kFusedStages, true, ldouble>(N, dt, mu, usec, k, work, slots, nullptr, 0, so, slots);
-  RecStep r = {ok ? 1 : 0, 1.0, 1.0, 0.0};
-  GSYNC();   // dz of every stage is in the slots
-  if (ok && k < N) {
-    const FusedWs &F = *Fp;
-    const size_t S = kFusedStages;
-    const FusedPtrs Ps = fused_ptrs(F, b);
+  const FusedWs &F = *Fp;
+  const size_t S = kFusedStages;
+  const int nxt = cur ^ 1;
+  const FusedPtrs Pw = fused_ptrs(F, b);
+  const V v{};
+  double ap = 1.0, ad = 1.0, gp = 0.0;
+  if (fresh && live) {
     StepIO<ldouble> io;
-    io.zc = Ps.pz[cur]; io.tc = Ps.pt[cur]; io.lc = Ps.pl[cur]; io.grow = Ps.pg[cur]; io.Jq = Ps.pj[cur];
-    io.gfa = Ps.pgf;
+    io.zc = Pw.pz[cur]; io.tc = Pw.pt[cur]; io.lc = Pw.pl[cur]; io.grow = Pw.pg[cur]; io.Jq = Pw.pj[cur];
+    io.gfa = Pw.pgf;
     io.SS = S; io.loff = (unsigned)k;
     io.dz = slots + DZ_OFF; io.SSd = 1; io.loffd = (unsigned)(k * GS);
-    const V v{};
-    step_body<C, ldouble, V>(v, io, k, mu, r.ap, r.ad, r.gp);
+    step_body<C, ldouble, V>(v, io, k, mu, ap, ad, gp);
+  }
+  ap = wave_min<kFusedStages>(ap); ad = wave_min<kFusedStages>(ad); gp = wave_sum<kFusedStages>(gp);
+  SweepStepRes r;
+  r.amin_p = fresh ? fmin(amin_p_in, ap) : amin_p_in;
+  r.amin_d = fresh ? fmin(amin_d_in, ad) : amin_d_in;
+  r.gphi = fresh ? gp : gphi_in;
+  const double alpha = nostep ? 0.0 : ldexp(r.amin_p, -ls), adual = nostep ? 0.0 : r.amin_d;
+  const Partials qn = {0, 0, 0, 0, 0, 0, 0, 0, 1e300, 0};
+  r.q = qn;
+  if (live) {
+    SweepIO<ldouble> io;
+    io.zc = Pw.pz[cur]; io.tc = Pw.pt[cur]; io.lc = Pw.pl[cur]; io.nc = Pw.pn[cur];
+    io.zn = Pw.pz[nxt]; io.tn = Pw.pt[nxt]; io.ln = Pw.pl[nxt]; io.nn = Pw.pn[nxt];
+    io.pp = Pw.pp; io.gro = Pw.pg[cur]; io.jqo = Pw.pj[cur]; io.grn = Pw.pg[nxt]; io.jqn = Pw.pj[nxt];
+    io.gfa = Pw.pgf;
+    io.SS = S; io.loff = (unsigned)k; io.kstride = 1u;
+    io.rec = slots + k * GS;
+    io.dzp = slots + DZ_OFF; io.nup = slots + DZ_OFF + NV;
+    io.SSd = 1; io.loffd = (unsigned)(k * GS); io.kstrided = (unsigned)GS;
+    io.wl = Pw.pwl; io.wn = Pw.pwn; io.warm = warm;
+    const SweepK sk = {N, dt, use_curv};
+    sweep_body<C, -1, ldouble, V, FIRSTC>(sk, v, io, k, FIRSTC != 0, nostep, alpha, adual, mu, r.q);
   }
   return r;
 }
@@ -2684,8 +2707,20 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
 #ifdef RMPC_STAMPS
     q.tk[0] = q.tk[1] = q.tk[2] = q.tk[3] = 0;
 #endif
+    // Generated views with LDS records: the step lengths of a fresh step are formed inside the sweep call (MERGE2).
+    // (The same reordering for the runtime tables, inline, is bit-identical too and no faster: boxer 0.48 vs 0.50 M.)
+    constexpr bool MERGE2 = V::SPEC && REC_LDS;
     park();
-    if constexpr (V::SPEC) {
+    SweepStepRes ssr;
+    bool fresh = false;
+    if constexpr (MERGE2) {
+      const bool nostep = first || (s.redo != 0);
+      fresh = act && !nostep && (s.newstep != 0);
+      const FusedWs *const Fp = (const FusedWs *)(Tp + 1);
+      if (first) ssr = fused_sweep_step_call<C, V, 1>(Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, act && stage, nostep, fresh, s.ls, s.amin_p, s.amin_d, gphi_sum, s.mu, warm ? 1 : 0);
+      else ssr = fused_sweep_step_call<C, V, 0>(Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, act && stage, nostep, fresh, s.ls, s.amin_p, s.amin_d, gphi_sum, s.mu, warm ? 1 : 0);
+      q = ssr.q;
+    } else if constexpr (V::SPEC) {
       // generated view: the sweep is a call (scalars in, partials out)
       if (act && stage) {
         const bool nostep = first || (s.redo != 0);
@@ -2729,6 +2764,9 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
       else sweep_body<C, -1, RP, V, 0>(sk, v, io, k, false, nostep, alpha, adual, s.mu, q);
     }
     unpark();
+    if constexpr (MERGE2) {
+      if (fresh) { s.amin_p = ssr.amin_p; s.amin_d = ssr.amin_d; gphi_sum = ssr.gphi; }
+    }
     Reduced r;
     r.f = wave_sum<LPI>(q.f); r.th = wave_sum<LPI>(q.th); r.lgs = wave_sum<LPI>(q.logs); r.sumc = wave_sum<LPI>(q.sumc);
     r.badf = wave_sum<LPI>(q.bad);
@@ -2748,16 +2786,8 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
     park();
     const double mu_r = s.mu;
     bool rec_ok = true;
-    constexpr bool RSTEP = V::SPEC && REC_LDS;   // recursion and step lengths in one call
     double ap = 1.0, ad = 1.0, gp = 0.0;
-    if constexpr (RSTEP) {
-      if (recurse) {
-        const FusedWs *const Fp = (const FusedWs *)(Tp + 1);
-        const RecStep rs = fused_recursion_step<C, V>(Fp, M.N, M.dt, mu_r, usec, b, s.cur, k, work, slots);
-        rec_ok = rs.ok != 0;
-        ap = rs.ap; ad = rs.ad; gp = rs.gp;
-      }
-    } else if (recurse) {
+    if (recurse) {
       bool ok;
       if constexpr (REC_LDS) {
         StepOut<ldouble> so;
@@ -2777,11 +2807,9 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
     GSYNC();   // dz, nunew
     STAMP_B(st_ric);
     // ---- step lengths of the new step -----------------------------------------------------------------
-    const bool stepping = act && (s.status == ST_ACTIVE) && (s.newstep != 0);
+    const bool stepping = !MERGE2 && act && (s.status == ST_ACTIVE) && (s.newstep != 0);
     park();
-    if constexpr (RSTEP) {
-      // (done with the recursion)
-    } else if constexpr (V::SPEC) {
+    if constexpr (V::SPEC) {
       if (stepping && stage) {
         const FusedWs *const Fp = (const FusedWs *)(Tp + 1);
         const StepRes sr = fused_step_call<C, V, REC_LDS>(Fp, b, s.cur, k, slots, s.mu);
