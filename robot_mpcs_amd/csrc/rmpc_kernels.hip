@@ -487,7 +487,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
   };
   constexpr int NFKC = []() { if constexpr (V::SPEC) return V::nfkrows() > 0 ? V::nfkrows() : 1; else return 1; }();
   FkBuf fkb[NFKC];
-  if constexpr (PIPE) {
+  if constexpr (V::SPEC) {   // (the rows of a generated view are static: their inputs are requested here, all at once)
     for_range<0, NFKC>([&](auto rc) __attribute__((always_inline)) {
       constexpr int r = decltype(rc)::value;
       if constexpr (r < V::nfkrows()) fk_load(r, fkb[r]);
