@@ -61,7 +61,10 @@ def parse():
     ap.add_argument("--no-legs", action="store_true", help="headline config only (no panda / boxer legs)")
     ap.add_argument("--no-full-chip", action="store_true", help="skip the one-launch-fills-the-chip leg (profiles: keeps the kernel average to launches of one batch)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the exclusive per-kernel leg")
-    ap.add_argument("--max-iter", type=int, default=25, help="cfg5 only: iteration cap of the real-time loop")
+    ap.add_argument("--max-iter", type=int, default=20, help="cfg5 only: iteration cap of the real-time loop")
+    ap.add_argument("--pass-budget", type=int, default=24, help="cfg5: real-time deadline of a solve in passes (horizon evaluations; 0 = none).  "
+                    "Not an iteration cap below --max-iter: 20 iterations fit in 21 passes; what it cuts are line searches that backtrack")
+    ap.add_argument("--pass-budget-boxer", type=int, default=40, help="cfg5: the boxers' deadline if it differs (0 = --pass-budget)")
     ap.add_argument("--acc-iters", type=int, default=3, help="cfg5: acceptable-termination window of the real-time loop (consecutive stagnant feasible iterations; the configs' default is 8)")
     ap.add_argument("--episode", type=int, default=40, help="cfg5 only: control steps per episode (then every instance restarts)")
     return ap.parse_args()
@@ -332,7 +335,9 @@ def main():
         part = fleet.partition_mixed(8192 * world, world)[rank]
         counts = {k: hi - lo for k, (lo, hi) in part.items()}
         shard = fleet.MixedFleetShard(counts, dev, seed=7 + rank, previous_plan=True, warm_duals=True,
-                                      options={"max_iter": args.max_iter, "acc_iters": args.acc_iters})
+                                      options={"max_iter": args.max_iter, "acc_iters": args.acc_iters},
+                                      pass_budget={"cfg2": args.pass_budget, "cfg3": args.pass_budget_boxer or args.pass_budget,
+                                                   "cfg4": args.pass_budget})
         for _ in range(max(3, args.warmup)):
             shard.tick()
         fence()
@@ -367,7 +372,7 @@ def main():
                           "iters_mean": float(a[:, 4].mean())}
             out = dict(base, value=total * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps,
                        config={"workload": WORKLOADS["cfg5"], "instances_per_gpu": 8192, "max_iter": args.max_iter,
-                               "acc_iters": args.acc_iters,
+                               "acc_iters": args.acc_iters, "pass_budget": args.pass_budget, "pass_budget_boxer": args.pass_budget_boxer or args.pass_budget,
                                "episode_steps": args.episode,
                                "warm_start": "shifted plan + multipliers (rmpc_set_warm_start)",
                                "parallelism": f"{world} x per-robot-type blocks (fleet.partition_mixed), no data-path collective"},

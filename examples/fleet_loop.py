@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--max-iter", type=int, default=0, help="iteration cap per solve (0 = the configs' 200)")
     ap.add_argument("--ls-max", type=int, default=0, help="step halvings allowed per line search (0 = the default 25)")
     ap.add_argument("--acc-iters", type=int, default=0, help="acceptable-termination window: consecutive stagnant feasible iterations (0 = the configs' 8)")
+    ap.add_argument("--pass-budget", type=int, default=0, help="real-time deadline of a solve in passes (rmpc_set_pass_budget; 0 = none)")
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the 8192-instance shard")
     ap.add_argument("--cold", action="store_true", help="current-state initialisation and cold multipliers every step")
     ap.add_argument("--no-warm-duals", action="store_true", help="shifted plan, but cold multipliers")
@@ -86,10 +87,11 @@ def main():
     if args.acc_iters > 0:
         opts["acc_iters"] = args.acc_iters
     shard = fleet.MixedFleetShard(counts, torch.device("cuda:0"), previous_plan=not args.cold,
-                                  warm_duals=not (args.cold or args.no_warm_duals), options=opts)
+                                  warm_duals=not (args.cold or args.no_warm_duals), options=opts,
+                                  pass_budget=args.pass_budget)
     times, stats = run_loop(shard, args.steps, args.warmup)
     print(json.dumps(summarize(shard, times, stats, {
-        "max_iter": args.max_iter or 200, "ls_max": args.ls_max or 25, "acc_iters": args.acc_iters or 8,
+        "max_iter": args.max_iter or 200, "ls_max": args.ls_max or 25, "acc_iters": args.acc_iters or 8, "pass_budget": args.pass_budget,
         "warm_start": "current_state, cold multipliers" if args.cold else
                       ("previous_plan" + ("" if args.no_warm_duals else " + multipliers"))})))
     shard.close()

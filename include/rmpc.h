@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RMPC_VERSION 103 /* 0.1.3: generated model views (rmpc_spec_source, rmpc_spec_name) */
+#define RMPC_VERSION 104 /* 0.1.4: rmpc_set_pass_budget; curvature terms of the arms */
 
 #define RMPC_MAX_JOINTS 8
 #define RMPC_MAX_LINKS 8
@@ -145,6 +145,15 @@ int rmpc_solve_batch_device(rmpc_handle *h, int B, const double *d_xinit,
  * previous solve failed starts from zero multipliers and mu0.  mode 0 (default): every solve starts cold.  Changing the mode, or solving another
  * batch size, forgets the stored multipliers. */
 int rmpc_set_warm_start(rmpc_handle *h, int mode);
+
+/* Real-time deadline of a solve, in passes (0 = none, the default).  A pass is one evaluation of the whole horizon:
+ * the start point, every trial point of a line search, every step recomputed with the Gauss-Newton blocks -- the
+ * unit the device pays for (an iteration costs one pass plus one per backtracking).  An instance still iterating
+ * when the budget is spent returns its last accepted iterate with exit flag 0, exactly as at the iteration limit;
+ * instances that finish earlier are unaffected.  No reference counterpart (FORCES Pro offers a wall-clock
+ * `solver_timeout`); used by the fleet loop, where a few instances in hopeless states would otherwise hold the
+ * control step of thousands.  Budgets below max_iter + 1 also bound the iterations. */
+int rmpc_set_pass_budget(rmpc_handle *h, int passes);
 
 /* Workspace size in bytes for a given descriptor / batch (no allocation). */
 int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch);

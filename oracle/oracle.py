@@ -81,6 +81,10 @@ def lib():
         L.orc_num_rows.argtypes = [C.POINTER(OrcDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_fk.restype = C.c_int
         L.orc_fk.argtypes = [C.POINTER(OrcDesc), dp, C.c_int, dp, dp]
+        L.orc_fk_curv.restype = C.c_int
+        L.orc_fk_curv.argtypes = [C.POINTER(OrcDesc), dp, C.c_int, dp, dp]
+        L.orc_stage_curvature.restype = C.c_int
+        L.orc_stage_curvature.argtypes = [C.POINTER(OrcDesc), dp, dp, dp, C.c_int, dp]
         L.orc_solve.restype = C.c_int
         L.orc_solve.argtypes = [C.POINTER(OrcDesc), dp, dp, dp, dp, C.POINTER(OrcStats), dp]
         L.orc_solve_warm.restype = C.c_int
@@ -158,6 +162,24 @@ class Oracle:
         rc = lib().orc_fk(C.byref(self.cd), _p(q), frame, _p(pos), _p(J))
         assert rc == 0, rc
         return pos, J
+
+    def fk_curv(self, q, frame, F):
+        """sum_c F_c d2 pos_c / dq dq of a frame (n x n)"""
+        q = np.ascontiguousarray(q, dtype=np.float64); F = np.ascontiguousarray(F, dtype=np.float64)
+        Cm = np.zeros((self.n, self.n))
+        rc = lib().orc_fk_curv(C.byref(self.cd), _p(q), frame, _p(F), _p(Cm))
+        assert rc == 0, rc
+        return Cm
+
+    def stage_curvature(self, z, p, lam, fixed_state=False):
+        """what the step computation subtracts from the Gauss-Newton q block when it uses the curvature terms"""
+        z = np.ascontiguousarray(z, dtype=np.float64); p = np.ascontiguousarray(p, dtype=np.float64)
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        assert lam.size == self.nh
+        Cm = np.zeros((self.n, self.n))
+        rc = lib().orc_stage_curvature(C.byref(self.cd), _p(z), _p(p), _p(lam), 1 if fixed_state else 0, _p(Cm))
+        assert rc == 0, rc
+        return Cm
 
     def eval_stage(self, z, p, derivs=True, dynamics=True, fixed_state=False):
         z = np.ascontiguousarray(z, dtype=np.float64); p = np.ascontiguousarray(p, dtype=np.float64)

@@ -6,6 +6,7 @@
 #include "rmpc_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -52,9 +53,18 @@ static void rot_axis(const double *k, double th, double *R) {
  * call sites: mpcBase.py:89-94, goal_reaching.py:22-27,
  * LinearConstraints.py:30-35, SelfCollisionAvoidanceConstraints.py:23-24) */
 /* ------------------------------------------------------------------ */
+static int fk_axes(const orc_desc *d, const double *q, int frame, double *pos, double *Jp, double (*ax)[3]);
+
 int orc_fk(const orc_desc *d, const double *q, int frame, double *pos, double *Jp) {
+  return fk_axes(d, q, frame, pos, Jp, 0);
+}
+
+/* ax (optional): world axis of the revolute joint behind each degree of freedom on the chain to `frame`
+ * (zero for prismatic joints and for degrees of freedom beyond the frame) */
+static int fk_axes(const orc_desc *d, const double *q, int frame, double *pos, double *Jp, double (*ax)[3]) {
   const int n = d->n;
   if (frame < 0 || frame >= d->n_joints) return -1;
+  if (ax) memset(ax, 0, sizeof(double) * 3 * n);
   for (int i = 0; i < 3 * n; i++) Jp[i] = 0.0;
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
   if (d->robot == ORC_ROBOT_DIFFDRIVE) {
@@ -101,10 +111,35 @@ int orc_fk(const orc_desc *d, const double *q, int frame, double *pos, double *J
       Jp[0 * n + dof] = aj[j][1] * r[2] - aj[j][2] * r[1];
       Jp[1 * n + dof] = aj[j][2] * r[0] - aj[j][0] * r[2];
       Jp[2 * n + dof] = aj[j][0] * r[1] - aj[j][1] * r[0];
+      if (ax) { ax[dof][0] = aj[j][0]; ax[dof][1] = aj[j][1]; ax[dof][2] = aj[j][2]; }
     } else if (d->joint_type[j] == ORC_JOINT_PRISMATIC) {
       Jp[0 * n + dof] = aj[j][0];
       Jp[1 * n + dof] = aj[j][1];
       Jp[2 * n + dof] = aj[j][2];
+    }
+  }
+  return 0;
+}
+
+/* Second derivatives of a frame position, contracted with a vector: C[a][b] += sum_c F_c d2 p_c / dq_a dq_b
+ * (C: n x n, symmetric).  For degrees of freedom a before b on the chain, dJ_b/dq_a = axis_a x J_b when joint a
+ * is revolute (it turns everything behind it, the column J_b included) and 0 when it is prismatic.  Degrees of
+ * freedom are numbered along the chain (joint_dof is increasing).  No reference counterpart: CasADi differentiates
+ * the forward kinematics symbolically for FORCES Pro's exact Hessian (mpcModel.py:139-160 generateSolver). */
+int orc_fk_curv(const orc_desc *d, const double *q, int frame, const double *F, double *Cacc) {
+  const int n = d->n;
+  double pos[3], Jp[3 * 8], ax[8][3];
+  if (d->robot != ORC_ROBOT_CHAIN) return -2;
+  int rc = fk_axes(d, q, frame, pos, Jp, ax);
+  if (rc != 0) return rc;
+  for (int a = 0; a < n; a++) {
+    /* G = F x axis_a, then F . (axis_a x J_b) = G . J_b */
+    const double G[3] = {F[1] * ax[a][2] - F[2] * ax[a][1], F[2] * ax[a][0] - F[0] * ax[a][2],
+                         F[0] * ax[a][1] - F[1] * ax[a][0]};
+    for (int b = a; b < n; b++) {
+      const double h = G[0] * Jp[0 * n + b] + G[1] * Jp[1 * n + b] + G[2] * Jp[2 * n + b];
+      Cacc[a * n + b] += h;
+      if (b != a) Cacc[b * n + a] += h;
     }
   }
   return 0;
@@ -243,6 +278,10 @@ int orc_num_rows(const orc_desc *d, int *nh_out, int *m_out) {
 /* second-order terms of the distance rows, filled by orc_eval_stage(want = 1) */
 static __thread double tl_C[ORC_NH_MAX][64];   /* n x n curvature matrix per general row (zero if none) */
 static __thread double tl_cw[ORC_NH_MAX];      /* extra weight from the inverse-barrier objective */
+static __thread double tl_G[64];               /* second-order term of the goal cost in q (models with_fk_curv) */
+
+/* models whose distance rows and goal cost carry second derivatives of the kinematics: the arms (n > 3) */
+static int with_fk_curv(const orc_desc *d) { return d->robot == ORC_ROBOT_CHAIN && d->ns == 0 && d->n > 3; }
 
 
 /* fixed_state != 0 (stage 1, whose state is pinned to xinit): rows that depend on the state
@@ -291,6 +330,12 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
           for (int i = 0; i < 3; i++) hab += 2.0 * w[i] * J[i * n + a] * J[i * n + b];
           H[a * nv + b] += hab;
         }
+      }
+      /* what Gauss-Newton leaves out: sum_i 2 w_i e_i grad^2 p_i (added to the Hessian with the curvature terms) */
+      memset(tl_G, 0, sizeof(double) * n * n);
+      if (with_fk_curv(d)) {
+        const double F[3] = {2.0 * w[0] * e[0], 2.0 * w[1] * e[1], 2.0 * w[2] * e[2]};
+        orc_fk_curv(d, q, d->end_frame, F, tl_G);
       }
     }
   }
@@ -342,6 +387,10 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
                 double jj = fJ[fr][0 * n + a] * fJ[fr][0 * n + bb] + fJ[fr][1 * n + a] * fJ[fr][1 * n + bb] + fJ[fr][2 * n + a] * fJ[fr][2 * n + bb];
                 tl_C[row][a * n + bb] = (jj - Jg[row * nv + a] * Jg[row * nv + bb]) / dist;
               }
+            if (with_fk_curv(d)) {
+              const double F[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist};
+              orc_fk_curv(d, q, fr, F, tl_C[row]);
+            }
           }
           row++;
         }
@@ -361,6 +410,10 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
           if (want)
             for (int a = 0; a < n; a++)
               Jg[row * nv + a] = sg * (pl[0] * fJ[fr][0 * n + a] + pl[1] * fJ[fr][1 * n + a] + pl[2] * fJ[fr][2 * n + a]) / nn;
+          if (want && with_fk_curv(d)) {
+            const double F[3] = {sg * pl[0] / nn, sg * pl[1] / nn, sg * pl[2] / nn};
+            orc_fk_curv(d, q, fr, F, tl_C[row]);
+          }
           row++;
         }
       }
@@ -386,6 +439,11 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
               for (int i = 0; i < 3; i++) jj += (fJ[fa][i * n + a] - fJ[fb][i * n + a]) * (fJ[fa][i * n + bb] - fJ[fb][i * n + bb]);
               tl_C[row][a * n + bb] = (jj - Jg[row * nv + a] * Jg[row * nv + bb]) / dist;
             }
+          if (with_fk_curv(d)) {
+            const double Fa[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist}, Fb[3] = {-Fa[0], -Fa[1], -Fa[2]};
+            orc_fk_curv(d, q, fa, Fa, tl_C[row]);
+            orc_fk_curv(d, q, fb, Fb, tl_C[row]);
+          }
         }
         row++;
       }
@@ -521,7 +579,7 @@ typedef struct {
   double *K, *kff, *P, *pv;
   double *dz, *dtt, *dlam, *nunew;
   double *zt, *tt, *gt, *xnt;
-  double *Cc, *cw;
+  double *Cc, *cw, *Gc;
 } orc_work;
 
 /* The workspace of a solve is kept per thread and reused while the dimensions stay the same: a fresh set of
@@ -545,7 +603,7 @@ static int work_slots(orc_work *w, const orc_desc *d, int m, orc_slot *sl) {
   SLOT(K, N * nw * nx, 1); SLOT(kff, N * nw, 1); SLOT(P, N * nx * nx, 1); SLOT(pv, N * nx, 1);
   SLOT(dz, N * nv, 1); SLOT(dtt, N * M, 1); SLOT(dlam, N * M, 1); SLOT(nunew, N * nx, 1);
   SLOT(zt, N * nv, 1); SLOT(tt, N * M, 1); SLOT(gt, N * MRM, 1); SLOT(xnt, N * nx, 1);
-  SLOT(Cc, N * ORC_NH_MAX * 64, 0); SLOT(cw, N * ORC_NH_MAX, 1);
+  SLOT(Cc, N * ORC_NH_MAX * 64, 0); SLOT(cw, N * ORC_NH_MAX, 1); SLOT(Gc, N * 64, 1);
 #undef SLOT
   return n;
 }
@@ -554,7 +612,7 @@ static void work_free(orc_work *w) {
   free(w->z); free(w->t); free(w->lam); free(w->nu); free(w->f); free(w->gf); free(w->H);
   free(w->g); free(w->Jg); free(w->xn); free(w->A); free(w->Bm); free(w->Q); free(w->qv);
   free(w->rc); free(w->K); free(w->kff); free(w->P); free(w->pv); free(w->dz); free(w->dtt);
-  free(w->dlam); free(w->nunew); free(w->zt); free(w->tt); free(w->gt); free(w->xnt); free(w->Cc); free(w->cw);
+  free(w->dlam); free(w->nunew); free(w->zt); free(w->tt); free(w->gt); free(w->xnt); free(w->Cc); free(w->cw); free(w->Gc);
 }
 
 /* the calling thread's workspace for these dimensions, zeroed like a fresh calloc (owned by the thread: not freed) */
@@ -591,11 +649,30 @@ static int eval_all(const orc_desc *d, orc_work *w, const double *params) {
       for (int r = 0; r < nh_used; r++)
         memcpy(w->Cc + ((size_t)k * ORC_NH_MAX + r) * 64, tl_C[r], sizeof(double) * d->n * d->n);
       memcpy(w->cw + (size_t)k * ORC_NH_MAX, tl_cw, sizeof(double) * nh_used);
+      if (d->has_goal) memcpy(w->Gc + (size_t)k * 64, tl_G, sizeof(double) * d->n * d->n);
     }
     if (r == ORC_EVAL_BAD_AVOID) rc = ORC_EVAL_BAD_AVOID;
     else if (r < 0) return r;
   }
   return rc;
+}
+
+/* Test access to the curvature terms of one stage: Cout [n*n] = sum_i (lam_i + cN/h_i^2) grad^2 h_i - (second-order
+ * term of the goal cost), i.e. what the step computation subtracts from the Gauss-Newton block when it uses them;
+ * lam [nh] multipliers of the general rows.  The exact Hessian of f - lam^T g in q is H_qq - Cout. */
+int orc_stage_curvature(const orc_desc *d, const double *z, const double *p, const double *lam, int fixed_state,
+                        double *Cout) {
+  static __thread double gf[NVM], H[NVM * NVM], g[MRM], Jg[MRM * NVM];
+  double f;
+  int nh = 0;
+  if (orc_num_rows(d, &nh, 0) != 0) return -1;
+  int r = orc_eval_stage(d, z, p, 1, &f, gf, H, g, Jg, 0, 0, 0, fixed_state);
+  if (r < 0 && r != ORC_EVAL_BAD_AVOID) return r;
+  const int n = d->n;
+  for (int a = 0; a < n * n; a++) Cout[a] = d->has_goal ? -tl_G[a] : 0.0;
+  for (int i = 0; i < nh; i++)
+    for (int a = 0; a < n * n; a++) Cout[a] += (lam[i] + tl_cw[i]) * tl_C[i][a];
+  return 0;
 }
 
 /* Cholesky of the nw x nw block, in place (lower). returns 0 ok */
@@ -790,7 +867,8 @@ static int frame_is_affine(const orc_desc *d, int f) {
   return 1;
 }
 static int model_uses_curvature(const orc_desc *d) {
-  if (d->robot != ORC_ROBOT_CHAIN || d->ns != 0 || d->n > 3) return 0;
+  if (d->robot != ORC_ROBOT_CHAIN || d->ns != 0) return 0;
+  if (with_fk_curv(d)) return 1;   /* the kinematics' own second derivatives are part of the terms */
   for (int mi = 0; mi < d->n_modules; mi++) {
     if (d->module_kind[mi] == ORC_MOD_RADIAL)
       for (int l = 0; l < d->n_links; l++) if (!frame_is_affine(d, d->link_frame[l])) return 0;
@@ -812,6 +890,15 @@ static int model_uses_curvature(const orc_desc *d) {
 static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, const double *params,
                       double *zout, orc_stats *st, double *trace, const double *lam_w, const double *nu_w,
                       double mu_w, double *lam_out, double *nu_out);
+
+/* development aid: ORC_TRACE=1 prints the residuals of every iteration to stderr */
+/* development aid: sweeps the GPU's pass kernels would need for the calling thread's last solve (one per trial point,
+ * one more per step recomputed with the Gauss-Newton blocks) */
+static __thread int tl_passes;
+int orc_last_passes(void) { return tl_passes; }
+static int orc_trace_stderr(void) {
+  return getenv("ORC_TRACE") != 0;
+}
 
 int orc_solve(const orc_desc *d, const double *xinit, const double *x0, const double *params,
               double *zout, orc_stats *st, double *trace) {
@@ -841,6 +928,7 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
   int gn_sticky = 0, curv_fail = 0, stall = 0;
   int ls_start = 0; /* step-length memory: halvings the next Gauss-Newton line search starts from */
   double obj_prev = 0.0;
+  tl_passes = 1;
   int ev = eval_all(d, w, params);
   if (ev != 0) { exitflag = (ev == ORC_EVAL_BAD_AVOID) ? -7 : -10; goto done; }
   if (lam_w) {
@@ -908,6 +996,9 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
       double *tr = trace + (size_t)it * ORC_TRACE_W;
       tr[0] = res_stat; tr[1] = res_eq; tr[2] = res_ineq; tr[3] = res_comp; tr[4] = mu; tr[5] = 0; tr[6] = obj; tr[7] = 0;
     }
+    if (orc_trace_stderr())
+      fprintf(stderr, "orc it %2d stat %.2e eq %.2e ineq %.2e comp %.2e mu %.2e obj %.10e rho %.2e\n", it, res_stat, res_eq,
+              res_ineq, res_comp, mu, obj, rho);
     if (!isfinite(res_stat) || !isfinite(res_eq) || !isfinite(res_ineq)) { exitflag = -6; break; }
     if (res_stat <= d->tol_stat && res_eq <= d->tol_eq && res_ineq <= d->tol_ineq && res_comp <= d->tol_comp) {
       exitflag = 1;
@@ -952,9 +1043,14 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
               for (int b2 = 0; b2 < d->n; b2++) Q[a2 * nv + b2] -= wgt * Cm[a2 * d->n + b2];
           }
         }
+        if (use_curv && d->has_goal) {
+          const double *G = w->Gc + (size_t)k * 64;
+          for (int a2 = 0; a2 < d->n; a2++)
+            for (int b2 = 0; b2 < d->n; b2++) Q[a2 * nv + b2] += G[a2 * d->n + b2];
+        }
       }
       if (riccati(w) != 0) {
-        if (use_curv) { use_curv = 0; continue; } /* this iteration only */
+        if (use_curv) { use_curv = 0; tl_passes++; continue; } /* this iteration only */
         fatal = 1;
         break;
       }
@@ -993,6 +1089,7 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
         for (size_t i = 0; i < (size_t)N * nv; i++) w->zt[i] = w->z[i] + alpha * w->dz[i];
         for (size_t i = 0; i < (size_t)N * m; i++) w->tt[i] = w->t[i] + alpha * w->dtt[i];
         double ft, tht, lst;
+        tl_passes++;
         if (trial_merit(d, w, params, mu, &ft, &tht, &lst) == 0) {
           double phi = ft - mu * lst + rho * tht;
           if (phi <= phi0 + ORC_ARMIJO * alpha * D + 1e-13 * fabs(phi0)) { accepted = 1; break; }
@@ -1002,16 +1099,21 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
       if (!accepted && use_curv) {
         /* Gauss-Newton fallback for this iteration; latched after repeated failures */
         if (++curv_fail >= ORC_CURV_FAIL_MAX) gn_sticky = 1;
+        tl_passes++;
         use_curv = 0;
         continue;
       }
       if (accepted && use_curv) curv_fail = 0;
+      /* the arms: a Gauss-Newton step accepted at full length releases the latch (the failures that set it
+       * belong to the first iterations of a warm start, where the fraction to the boundary cuts the steps) */
+      if (accepted && !use_curv && ls == 0 && with_fk_curv(d)) { gn_sticky = 0; curv_fail = 0; }
       if (accepted) ls_start = ls > ORC_LS_GROW ? ls - ORC_LS_GROW : 0;
       break;
     }
     if (fatal) { exitflag = -5; break; }
     if (!accepted) { exitflag = -8; break; } /* line search failure */
     if (trace) { trace[(size_t)it * ORC_TRACE_W + 5] = alpha; trace[(size_t)it * ORC_TRACE_W + 7] = ls; }
+    if (orc_trace_stderr()) fprintf(stderr, "       step alpha %.3e ls %d ad %.3e curv %d\n", alpha, ls, ad, use_curv);
     memcpy(w->z, w->zt, sizeof(double) * N * nv);
     memcpy(w->t, w->tt, sizeof(double) * N * m);
     for (size_t i = 0; i < (size_t)N * m; i++) w->lam[i] += ad * w->dlam[i];

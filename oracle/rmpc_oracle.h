@@ -115,6 +115,11 @@ int orc_num_rows(const orc_desc *d, int *nh, int *m);
 
 /* forward kinematics of frame `frame` (position, 3 x n Jacobian row-major) */
 int orc_fk(const orc_desc *d, const double *q, int frame, double *pos, double *Jp);
+/* Cacc [n*n] += sum_c F_c d2 pos_c / dq dq (holonomic chain) */
+int orc_last_passes(void);
+int orc_stage_curvature(const orc_desc *d, const double *z, const double *p, const double *lam, int fixed_state,
+                        double *Cout);
+int orc_fk_curv(const orc_desc *d, const double *q, int frame, const double *F, double *Cacc);
 
 typedef struct orc_stats {
   int32_t exitflag; /* 1 converged, 2 acceptable (objective stagnated at a feasible point), 0 iteration cap, <0 failure */

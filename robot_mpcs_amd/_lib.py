@@ -70,7 +70,7 @@ class RmpcScene(C.Structure):
 # every symbol include/rmpc.h declares
 EXPORTED_SYMBOLS = [
     "rmpc_version", "rmpc_source_hash", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
-    "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_warm_start", "rmpc_set_profiling", "rmpc_get_profile",
+    "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_warm_start", "rmpc_set_pass_budget", "rmpc_set_profiling", "rmpc_get_profile",
     "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep", "rmpc_spec_source", "rmpc_spec_name", "rmpc_spec_for", "rmpc_debug_poison_lds",
     "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_advance_device", "rmpc_advance_device_flags", "rmpc_free_space_device",
 ]
@@ -156,6 +156,8 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_get_profile.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int64), dp, C.POINTER(C.c_int64)]
     L.rmpc_kernel_name.restype = C.c_char_p
     L.rmpc_kernel_name.argtypes = [C.c_int]
+    L.rmpc_set_pass_budget.restype = C.c_int
+    L.rmpc_set_pass_budget.argtypes = [C.c_void_p, C.c_int]
     L.rmpc_last_passes.restype = C.c_int
     L.rmpc_last_passes.argtypes = [C.c_void_p]
     L.rmpc_debug_sweep.restype = C.c_int
@@ -382,6 +384,11 @@ class Solver:
         """Closed loops: start every solve from the multipliers of the previous solve of the same batch
         (``rmpc_set_warm_start``); the plan itself is warm-started through ``x0`` as in the reference."""
         self._check(self._L.rmpc_set_warm_start(self._h, 1 if enable else 0), "rmpc_set_warm_start")
+
+    def set_pass_budget(self, passes: int):
+        """Real-time deadline of a solve in passes (``rmpc_set_pass_budget``; 0 = none): instances still iterating
+        when it is spent return their last accepted iterate with exit flag 0."""
+        self._check(self._L.rmpc_set_pass_budget(self._h, int(passes)), "rmpc_set_pass_budget")
 
     def set_profiling(self, enable: bool):
         self._check(self._L.rmpc_set_profiling(self._h, 1 if enable else 0), "rmpc_set_profiling")

@@ -747,6 +747,9 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
     if (SL >= v.nslots()) return;
     Vec3 J[NQ];
     const Vec3 Pt = kin.template point<SL>(v, J);
+    // (FKCURV) sum over the slot's rows of (multiplier + inverse-barrier weight) x unit direction of the row, minus
+    // the goal cost's 2 w e: what the second derivatives of the slot's point are contracted with
+    Vec3 Fc = {0, 0, 0};
     if (SL == 0 && v.has_goal()) {
       // GoalReaching (goal_reaching.py:19-33), Gauss-Newton Hessian
       const double e0 = Pt.x - goalv[0], e1 = Pt.y - goalv[1], e2 = Pt.z - goalv[2];
@@ -759,6 +762,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         for (int c = a; c < NQ; c++)
           Qqq[a][c] += 2.0 * (w0 * J[a].x * J[c].x + w1 * J[a].y * J[c].y + w2 * J[a].z * J[c].z);
       }
+      if constexpr (C::FKCURV) Fc = {-2.0 * w0 * e0, -2.0 * w1 * e1, -2.0 * w2 * e2};
     }
     auto fk_row_body = [&](const int r, const FkBuf &Bf) __attribute__((always_inline)) {
       const int i = v.fk_row(r), kind = v.fk_kind(r);
@@ -772,12 +776,14 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
       }
       double gq[NQ];
       double h, cinv = 0.0;
+      Vec3 nd = {0, 0, 0};   // unit direction of the row in the slot's point (FKCURV)
       if (kind == ROW_RADIAL) {
         // ||fk_l(q) - c_i|| - r_i - r_body (mpcBase.py:82-101)
         const Vec3 dv = {Pt.x - Bf.op[0], Pt.y - Bf.op[1], Pt.z - Bf.op[2]};
         const double dist = sqrt(dot(dv, dv));
         h = dist - Bf.op[3] - rbody;
         cinv = 1.0 / dist;
+        if constexpr (C::FKCURV) nd = {dv.x * cinv, dv.y * cinv, dv.z * cinv};
 #pragma unroll
         for (int a = 0; a < NQ; a++) gq[a] = dot(dv, J[a]) * cinv;
       } else if (kind == ROW_LINEAR) {
@@ -787,6 +793,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         const double sd = dot(av, Pt) + Bf.op[3];
         const double sgn = sd < 0 ? -1.0 : 1.0;
         h = fabs(sd) / nrm - rbody;
+        if constexpr (C::FKCURV) nd = {sgn * av.x / nrm, sgn * av.y / nrm, sgn * av.z / nrm};
 #pragma unroll
         for (int a = 0; a < NQ; a++) gq[a] = sgn * dot(av, J[a]) / nrm;
       } else {
@@ -794,6 +801,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         const double dist = sqrt(dot(Pt, Pt));
         h = dist - 2.0 * rbody;
         cinv = 1.0 / dist;
+        if constexpr (C::FKCURV) nd = {Pt.x * cinv, Pt.y * cinv, Pt.z * cinv};
 #pragma unroll
         for (int a = 0; a < NQ; a++) gq[a] = dot(Pt, J[a]) * cinv;
       }
@@ -802,6 +810,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
       if (k == 0 && NS == 0) {
         h = 1.0;
         cinv = 0.0;
+        nd = {0, 0, 0};
 #pragma unroll
         for (int a = 0; a < NQ; a++) gq[a] = 0.0;
       }
@@ -853,6 +862,10 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         for (int a = 0; a < NQ; a++)
 #pragma unroll
           for (int c = a; c < NQ; c++) Cqq[a][c] += wgt * (dot(J[a], J[c]) - gq[a] * gq[c]);
+        if constexpr (C::FKCURV) {
+          const double wf = rw.lv + cw;
+          Fc.x += wf * nd.x; Fc.y += wf * nd.y; Fc.z += wf * nd.z;
+        }
       }
     };
     if constexpr (V::SPEC) {
@@ -865,6 +878,20 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
       for (int r = v.slot_row_begin(SL); r < v.slot_row_begin(SL + 1); r++) {
         fk_load(r, fkb[0]);   // requests first, arithmetic after
         fk_row_body(r, fkb[0]);
+      }
+    }
+    if constexpr (C::FKCURV) {
+      // second derivatives of the slot's point: for joints a before c on the chain dJ_c/dq_a = axis_a x J_c when
+      // joint a is revolute (it turns everything behind it, the column J_c included), 0 when it is prismatic;
+      // Fc . (axis_a x J_c) = (Fc x axis_a) . J_c.  Columns beyond the slot's frames are zero.
+      if (M.use_curv) {
+#pragma unroll
+        for (int a = 0; a < NQ; a++) {
+          if (v.joint_type(a) != RMPC_JOINT_REVOLUTE) continue;
+          const Vec3 G = cross(Fc, kin.aj[a]);
+#pragma unroll
+          for (int c = a; c < NQ; c++) Cqq[a][c] += dot(G, J[c]);
+        }
       }
     }
   };
@@ -1206,6 +1233,11 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
       return false;  // next sweep retries with alpha / 2
     }
     if (usedc) s.curv_fail = 0;
+    // the arms: a Gauss-Newton step accepted at full length releases the latch (the failures that set it belong to
+    // the first iterations of a warm start, where the fraction to the boundary cuts the steps)
+    if constexpr (C::FKCURV) {
+      if (!usedc && ls == 0) { s.gn_sticky = 0; s.curv_fail = 0; }
+    }
     // step-length memory: the next Gauss-Newton line search starts one halving above the accepted one (models
     // whose steps overshoot every iteration -- the unicycle -- otherwise pay a pass per halving per iteration)
     lsst = ls > kLsGrow ? ls - kLsGrow : 0;
@@ -3082,6 +3114,7 @@ struct rmpc_handle {
   int Bp = 0;
   int variant = -1;
   int max_passes = 0;
+  int pass_budget = 0;            // rmpc_set_pass_budget (0: none)
   void *ws_base = nullptr;
   size_t ws_bytes = 0;
   hipStream_t stream = nullptr;
@@ -3304,15 +3337,16 @@ static int build_model(const rmpc_desc &d, DevModel &M, std::string &err) {
   M.acc_iters = d.acc_iters < 0 ? 0 : d.acc_iters;
   M.acc_obj_tol = d.acc_obj_tol > 0 ? d.acc_obj_tol : 1e-8;
   M.ls_max = d.ls_max > 0 ? d.ls_max : kLsMax;
-  // exact curvature of the distance rows: holonomic chain, no slack, n <= 3 and every frame a
+  // exact curvature of the distance rows: holonomic chain, no slack, and for n <= 3 every frame a
   // distance row refers to moves affinely with q (prismatic joints, or revolute at the frame itself)
   auto affine = [&](int f) {
     for (int j = 0; j <= f; j++)
       if (d.joint_type[j] == RMPC_JOINT_REVOLUTE && j != f) return false;
     return true;
   };
-  bool curv = d.robot == RMPC_ROBOT_CHAIN && d.ns == 0 && d.n <= 3;
-  for (int mi = 0; mi < d.n_modules && curv; mi++) {
+  bool curv = d.robot == RMPC_ROBOT_CHAIN && d.ns == 0;
+  // (the arms carry the kinematics' own second derivatives: Cfg::FKCURV)
+  for (int mi = 0; mi < d.n_modules && curv && d.n <= 3; mi++) {
     if (d.module_kind[mi] == RMPC_MOD_RADIAL)
       for (int l = 0; l < d.n_links; l++) curv = curv && affine(d.link_frame[l]);
     if (d.module_kind[mi] == RMPC_MOD_SELFCOLLISION)
@@ -3706,7 +3740,8 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
   if (h->have_duals && h->duals_B != B) h->have_duals = false;   // multipliers of another batch: cold start
   if (h->fused) {
     // one launch: every wavefront carries its two instances from the first sweep to the plan
-    const int cap = max_passes_override > 0 ? max_passes_override : h->max_passes;
+    int cap = max_passes_override > 0 ? max_passes_override : h->max_passes;
+    if (h->pass_budget > 0 && h->pass_budget < cap) cap = h->pass_budget;
     HIPCHK(hipMemsetAsync(h->F.passes, 0, sizeof(int), st));
     {
       ProfScope ps(h, st, K_FUSED);
@@ -3733,7 +3768,8 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
     hipLaunchKernelGGL(k_init, dim3((B + 255) / 256), dim3(256), 0, st, h->W, d_xinit, B, M.nx, M.mu0,
                        (h->warm_mode && h->have_duals) ? 1 : 0);
   }
-  const int cap = max_passes_override > 0 ? max_passes_override : h->max_passes;
+  int cap = max_passes_override > 0 ? max_passes_override : h->max_passes;
+  if (h->pass_budget > 0 && h->pass_budget < cap) cap = h->pass_budget;
   int pass = 0, next_check = 8;
   Phase ph{h->W, B};
   bool migrated = false;
@@ -4065,6 +4101,13 @@ int rmpc_set_warm_start(rmpc_handle *h, int mode) {
   if (!h) return fail("null handle");
   h->warm_mode = mode ? 1 : 0;
   h->have_duals = false;
+  return 0;
+}
+
+int rmpc_set_pass_budget(rmpc_handle *h, int passes) {
+  if (!h) return fail("null handle");
+  if (passes < 0) return fail("pass budget must be >= 0");
+  h->pass_budget = passes;
   return 0;
 }
 

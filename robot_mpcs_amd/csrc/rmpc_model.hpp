@@ -156,7 +156,13 @@ struct Cfg {
   static constexpr int NW = NS_ + NU;
   static constexpr int NQ2 = NQ_ * (NQ_ + 1) / 2;
   static constexpr int NR = 5;  // reduced diff-drive state (x, y, theta, v, omega)
-  static constexpr bool CURV = (ROBOT_ == RMPC_ROBOT_CHAIN) && (NS_ == 0) && (NQ_ <= 3);
+  // exact curvature of the distance rows / inverse-barrier objective (Cqq block of the stage record): holonomic
+  // chains without slack.  Three joints: only when every frame moves affinely with q (decided per descriptor,
+  // DevModel::use_curv).  The arms: always, with the second derivatives of the kinematics themselves (FKCURV:
+  // distance rows, inverse-barrier objective and the goal cost) -- without them a warm-started arm crawls to the
+  // tolerance at a linear rate of 0.6 per iteration.
+  static constexpr bool CURV = (ROBOT_ == RMPC_ROBOT_CHAIN) && (NS_ == 0);
+  static constexpr bool FKCURV = CURV && (NQ_ > 3);
   // instances (wavefronts) per block of the grouped Riccati kernel.  Small blocks: with the instance-major
   // records neighbouring instances no longer share cache lines, a 4-wavefront block fits beside a k_sweep
   // wavefront of another batch on every SIMD (a 16-wavefront block needs four free slots per SIMD at once);

@@ -94,10 +94,12 @@ class MixedFleetShard:
     stream; ``tick()`` runs one control step of all of them: parameters expanded from the compact scene on the
     device (``rmpc_solve_batch_scene_device``, counterpart of the planner setters, mpcPlanner.py:83-210), solve,
     plant step with the model's ERK2 map and warm start of the next solve (``rmpc_advance_device``; shifted
-    plan = ``shiftHorizon``, mpcPlanner.py:215-226).  Nothing crosses PCIe between control steps."""
+    plan = ``shiftHorizon``, mpcPlanner.py:215-226).  Nothing crosses PCIe between control steps.  ``pass_budget``
+    (one number, or one per block name): deadline of every solve in passes (instances still iterating return their
+    last accepted iterate, flag 0)."""
 
     def __init__(self, counts: dict, device, seed: int = 7, previous_plan: bool = True, warm_duals: bool = True,
-                 options: dict | None = None):
+                 options: dict | None = None, pass_budget=0):
         import torch
         from robot_mpcs_amd._lib import Solver
         from robot_mpcs_amd import scenarios as sn
@@ -119,6 +121,9 @@ class MixedFleetShard:
                 d["options"] = dict(d["options"], **options)
             s = Solver(d, max_batch=B, device=dev_index)
             s.set_warm_start(bool(warm_duals and previous_plan))
+            pb = pass_budget.get(name, 0) if isinstance(pass_budget, dict) else int(pass_budget)
+            if pb > 0:
+                s.set_pass_budget(pb)   # real-time deadline of a control step (rmpc_set_pass_budget)
             ten = dict(goal=t(sc.extra["goal"]), r_body=t(np.full(B, sc.extra["r_body"])),
                        lower_limits=t(np.tile(lim[0], (B, 1))), upper_limits=t(np.tile(lim[1], (B, 1))),
                        lower_limits_u=t(np.tile(limu[0], (B, 1))), upper_limits_u=t(np.tile(limu[1], (B, 1))))

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Development aid (CPU, oracle only): warm-started closed loop of a few instances; prints per control step the exit
+flags, iterations and final residuals, and with ORC_TRACE=1 the residuals of every iteration of the traced steps.
+    python scripts/dev_oracle_loop.py cfg4 4 25 [trace_step]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.oracle import Oracle
+from robot_mpcs_amd.scenarios import make_scenario
+name = sys.argv[1]; B = int(sys.argv[2]); steps = int(sys.argv[3])
+opts = {"max_iter": 20, "acc_iters": 3}
+sc = make_scenario(name, B=B, seed=7)
+d = dict(sc.desc); d["options"] = dict(d["options"], **opts)
+o = Oracle(d)
+nx, nv, N, nxs = o.nx, o.nv, o.N, o.nx + o.ns
+x = sc.xinit.copy(); x0 = sc.x0.copy(); duals = [None] * B
+for t in range(steps):
+    row = []
+    for b in range(B):
+        r = o.solve_warm(x[b], x0[b], sc.params[b], duals[b])
+        duals[b] = r["duals"] if r["exitflag"] >= 0 else (np.zeros((N, o.m)), np.zeros((N, nx)), d["options"]["mu0"] / 1000.0)
+        row.append("f%d it%2d st %.1e eq %.1e in %.1e cp %.1e mu %.1e" % (r["exitflag"], r["iters"], r["res_stat"], r["res_eq"], r["res_ineq"], r["res_comp"], r["mu"]))
+        x[b] = o.dynamics(x[b], r["z"][0, nxs:])
+        x0[b] = np.concatenate([r["z"][1:], r["z"][-1:]])
+    print(t, " | ".join(row), flush=True)

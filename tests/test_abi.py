@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_descriptor_layout_and_version(lib):
     L = lib.load_library()
     assert L.rmpc_desc_size() == C.sizeof(lib.RmpcDesc)
-    assert L.rmpc_version() == 103
+    assert L.rmpc_version() == 104
     assert [L.rmpc_kernel_name(i).decode() for i in range(5)] == ["k_pack", "k_sweep", "k_riccati", "k_step", "k_unpack"]
 
 

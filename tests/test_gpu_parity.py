@@ -475,3 +475,34 @@ def test_device_entry_is_ordered_with_the_callers_stream(rt):
         assert torch.equal(zsum, z.sum(dim=(1, 2)))       # the consumer op saw the finished plan, not the NaN fill
         del junk
     s.close()
+
+
+@pytest.mark.parametrize("name,B,budget", [("cfg4", 96, 13), ("cfg2", 128, 14), ("cfg3", 64, 24)])
+def test_pass_budget_cuts_only_the_unfinished(rt, name, B, budget):
+    """rmpc_set_pass_budget: instances that finish within the budget return exactly what they return without one;
+    the others come back with exit flag 0 and their last accepted iterate; the instances cut are those the
+    oracle needs more passes for (one per horizon evaluation: start point, trial points, recomputed steps)."""
+    from oracle.oracle import lib as olib
+    sc = rt["make_scenario"](name, B=B, seed=19)
+    s = rt["Solver"](sc.desc, max_batch=B)
+    free = s.solve(sc.xinit, sc.x0, sc.params)
+    s.set_pass_budget(budget)
+    cut = s.solve(sc.xinit, sc.x0, sc.params)
+    if name == "cfg4":
+        assert s.last_passes() <= budget
+    s.set_pass_budget(0)
+    again = s.solve(sc.xinit, sc.x0, sc.params)
+    s.close()
+    assert np.array_equal(again["exitflag"], free["exitflag"]) and np.array_equal(again["z"], free["z"])
+    done = cut["exitflag"] != 0
+    assert 0 < done.sum() < B, (done.sum(), "choose a budget that cuts some instances and not all")
+    assert np.array_equal(cut["exitflag"][done], free["exitflag"][done])
+    assert np.array_equal(cut["iters"][done], free["iters"][done])
+    assert np.array_equal(cut["z"][done], free["z"][done])
+    assert np.all(np.isfinite(cut["z"][~done])) and np.all(cut["iters"][~done] < budget)
+    o = rt["Oracle"](sc.desc)
+    passes = np.zeros(B, dtype=int)
+    for b in range(B):
+        o.solve(sc.xinit[b], sc.x0[b], sc.params[b])
+        passes[b] = olib().orc_last_passes()
+    assert ((passes <= budget) == done).mean() >= 0.9, (passes, done)

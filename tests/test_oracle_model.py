@@ -156,3 +156,51 @@ def test_vel_limit_rows_follow_the_reference_module(oracle_lib):
     expect = d["N"] * (w[0] / e["g"][0] + w[2] / e["g"][2] + w[3] / e["g"][r0] + w[4] / e["g"][r0 + 4])
     base = dict(d); base["has_avoid"] = 0
     np.testing.assert_allclose(e["f"] - Oracle(base).eval_stage(z, p)["f"], expect, rtol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["cfg4", "panda", "wc_panda", "cfg2", "pointRobot"])
+def test_curvature_terms_complete_the_gauss_newton_block(name, oracle_lib):
+    """H_qq (Gauss-Newton) minus the curvature terms is the exact Hessian of f - lam^T g in q: differences of the
+    numpy restatement's gradient.  For the arms the terms include the second derivatives of the forward kinematics
+    (distance rows, inverse-barrier objective and goal cost); the three-joint models with affine frames have none."""
+    sc = make_scenario(name, B=4, seed=5)
+    o = Oracle(sc.desc)
+    d = sc.desc
+    rng = np.random.default_rng(3)
+    n = o.n
+    for z, p in _random_points(sc, o, rng, k=3):
+        lam = rng.uniform(0.0, 2.0, size=o.nh)
+        e = o.eval_stage(z, p)
+        Cm = o.stage_curvature(z, p, lam)
+        np.testing.assert_allclose(Cm, Cm.T, atol=1e-12 * max(1.0, np.abs(Cm).max()))
+
+        def lagr(zz):
+            return ref.stage_cost(d, zz, p) - lam @ ref.stage_ineq(d, zz, p)[: o.nh]
+
+        def grad_q(qq):
+            zz = z.copy(); zz[:n] = qq
+            return ref.fd_grad(lagr, zz, eps=1e-6)[0][:n]
+
+        Hfd = ref.fd_grad(grad_q, z[:n].copy(), eps=1e-4)
+        Hfd = 0.5 * (Hfd + Hfd.T)
+        Hex = e["H"][:n, :n] - Cm
+        # (the Gauss-Newton block holds sigma-free terms only: eval_stage's H is the objective's block)
+        scale = max(1.0, np.abs(Hfd).max())
+        np.testing.assert_allclose(Hex, Hfd, atol=2e-4 * scale)
+
+
+def test_fk_second_derivatives_match_differences_of_the_jacobian(oracle_lib):
+    sc = make_scenario("panda", B=1, seed=2)
+    o = Oracle(sc.desc)
+    rng = np.random.default_rng(8)
+    for frame in sorted({int(sc.desc["end_frame"])} | {int(f) for f in sc.desc["link_frame"]}):
+        q = rng.uniform(-1.5, 1.5, size=o.n)
+        F = rng.normal(size=3)
+        Cm = o.fk_curv(q, frame, F)
+        eps = 1e-6
+        Cfd = np.zeros((o.n, o.n))
+        for b in range(o.n):
+            qp = q.copy(); qp[b] += eps
+            qm = q.copy(); qm[b] -= eps
+            Cfd[:, b] = F @ (o.fk(qp, frame)[1] - o.fk(qm, frame)[1]) / (2 * eps)
+        np.testing.assert_allclose(Cm, Cfd, atol=1e-8)
