@@ -2485,6 +2485,8 @@ struct FusedWs {
   double *R;                      // [B][N][rs]   (models whose records do not fit LDS)
   double *KP;                     // [B][N][kps]
   int *passes;                    // [1] most passes any instance of the last launch needed
+  int *lastp;                     // [B] passes of every instance in the last launch
+  int *order;                     // [B] launch order of the next warm-started launch: instances by lastp, longest first
   long long *stamps;              // [blocks][8] cycles per phase (builds with -DRMPC_STAMPS only; development aid)
   int rs, kps, nv, m, nx, npar, nhs, njqs;
 };
@@ -2662,16 +2664,21 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
                                               const double *__restrict__ params, double *__restrict__ zout,
                                               int *__restrict__ exitflag, int *__restrict__ iters_out,
                                               double *__restrict__ kkt, double *__restrict__ obj, const int max_passes,
-                                              const int warm_mode) {
+                                              const int warm_mode, const int use_order) {
   constexpr int LPI = kFusedStages;
   constexpr int IPW = 2;   // instances per wavefront
   constexpr int NX = C::NX, NV = C::NV;
   const V v(M, *Tp);
   const int half = threadIdx.x / LPI;
   const int k = threadIdx.x & (LPI - 1);       // stage of this lane; also its lane index inside the instance
-  const int bi = blockIdx.x * IPW + half;
-  const bool valid = bi < B;
-  const size_t b = valid ? bi : B - 1;          // clamped: addresses stay legal, nothing is written for !valid
+  // Workgroups are dispatched in index order and every SIMD holds one of these wavefronts for its whole solve: the
+  // launch ends with the wavefronts that started last.  In a closed loop (use_order) the instances are taken in the
+  // order of their previous solve's passes, longest first (k_order), so that the long solves start first and pair up;
+  // the arithmetic of an instance does not depend on its slot.
+  const int slot = blockIdx.x * IPW + half;
+  const bool valid = slot < B;
+  const int bi = valid ? (use_order ? F.order[slot] : slot) : B - 1;
+  const size_t b = bi;                          // (!valid: clamped -- addresses stay legal, nothing is written)
   const int N = M.N;
   const bool stage = k < N;
 
@@ -2688,6 +2695,8 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
   const size_t S = kFusedStages;
   // the solver words of the two instances are parked here around the phase calls (the callees own the register file)
   __shared__ Inst sinst[IPW];
+  __shared__ int spass[IPW];     // passes in which the instance was still iterating
+  if (k == 0) spass[half] = 0;
   // ---- prologue: ABI rows of this stage -> the instance's block (x_1 := xinit, mpcModel.py:108) -------
   const FusedPtrs P0 = fused_ptrs(F, b);
   if (valid && stage) {
@@ -2732,6 +2741,7 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
   for (; pass < max_passes; pass++) {
     const bool act = (s.status == ST_ACTIVE);
     if (__ballot(act) == 0ull) break;
+    if (act && k == 0) spass[half]++;
     const bool first = (pass == 0);
     STAMP_A();
     // ---- sweep: trial point, model functions, condensing, stage partials -------------------------------
@@ -2900,8 +2910,35 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
     kkt[b] = fmax(fmax(s.res_stat, s.res_eq), fmax(s.res_ineq, s.res_comp));
     obj[b] = s.obj;
     F.wmu[b] = ((s.status == ST_ACTIVE || s.status >= 0) && isfinite(s.mu) && s.mu > 0.0) ? s.mu : M.mu0;
+    F.lastp[b] = spass[half];
   }
   if (threadIdx.x == 0) atomicMax(F.passes, pass);
+}
+
+// Launch order of a warm-started fused launch: the instances sorted by the passes of their previous solve, longest
+// first (counting sort, one block; the order inside a bucket is whatever the atomics give -- it changes which
+// instances share a wavefront, never what an instance computes).
+__global__ __launch_bounds__(1024) void k_order(const int *__restrict__ key, int *__restrict__ order, int B) {
+  __shared__ int cnt[256];
+  const int tid = threadIdx.x;
+  if (tid < 256) cnt[tid] = 0;
+  __syncthreads();
+  for (int b = tid; b < B; b += 1024) {
+    int kq = key[b];
+    kq = kq < 0 ? 0 : (kq > 255 ? 255 : kq);
+    atomicAdd(&cnt[255 - kq], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; i++) { const int c = cnt[i]; cnt[i] = run; run += c; }
+  }
+  __syncthreads();
+  for (int b = tid; b < B; b += 1024) {
+    int kq = key[b];
+    kq = kq < 0 ? 0 : (kq > 255 ? 255 : kq);
+    order[atomicAdd(&cnt[255 - kq], 1)] = b;
+  }
 }
 
 // ===========================================================================
@@ -3135,7 +3172,7 @@ struct rmpc_handle {
   double prof_bytes[RMPC_NUM_KERNELS] = {0};     // accumulated algorithmic bytes of the profiled launches
   std::vector<int> h_hist;
   // debugging switches, read once at rmpc_create (never set by the product code)
-  bool env_no_migrate = false, env_dump_hist = false;
+  bool env_no_migrate = false, env_dump_hist = false, env_no_order = false;
 };
 
 // Row tables in device memory (DevTables): kinematic slots with their FK rows, and the
@@ -3688,6 +3725,8 @@ static size_t carve_fused(const DevModel &M, int Bcap, void *base, FusedWs &F) {
   F.kps = (M.nw * M.nx + M.nw + M.nx * (M.nx + 1) / 2 + M.nx + M.nx + 7) / 8 * 8;
   F.KP = c.take<double>((size_t)Bcap * M.N * F.kps);
   F.passes = c.take<int>(64);
+  F.lastp = c.take<int>(Bcap);
+  F.order = c.take<int>(Bcap);
   F.stamps = c.take<long long>((size_t)Bcap * 8);
   return (c.off + 255) & ~(size_t)255;
 }
@@ -3706,8 +3745,11 @@ static int launch_fused_t(rmpc_handle *h, int B, const double *d_xinit, const do
                           double *d_zout, int *d_exit, int *d_iters, double *d_kkt, double *d_obj, hipStream_t st, int cap) {
   const int warm = (h->warm_mode && h->have_duals) ? 1 : 0;
   if (h->F.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
+  // closed loop: the previous solve of this batch tells which instances take long (k_fused: launch order)
+  const int use_order = (warm && !h->env_no_order) ? 1 : 0;
+  if (use_order) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const int *)h->F.lastp, h->F.order, B);
   hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, V>), dim3((B + 1) / 2), dim3(64), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
-                     d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm);
+                     d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm, use_order);
   return 0;
 }
 static int launch_fused(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
@@ -3949,6 +3991,7 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_passes, sizeof(int), hipHostMallocDefault);
   if (e != hipSuccess) { rmpc_destroy(h); return fail(std::string("stream / pinned word: ") + hipGetErrorString(e)); }
   h->env_no_migrate = getenv("RMPC_NO_MIGRATE") != nullptr;
+  h->env_no_order = getenv("RMPC_NO_ORDER") != nullptr;   // (development switch: fused launches in index order)
   h->env_dump_hist = getenv("RMPC_DUMP_HIST") != nullptr;
   *out = h;
   return 0;

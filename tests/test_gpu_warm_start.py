@@ -130,3 +130,27 @@ def test_mixed_fleet_shard_closed_loop(rt):
         # (the NLP is non-convex: a cold and a warm start may settle in different local solutions for a few instances)
         assert tried >= 8 and same >= 0.75 * tried, (f["name"], tried, same)
     shard.close()
+
+
+@pytest.mark.parametrize("name,B", [("cfg2", 333), ("cfg3", 200)])
+def test_launch_order_of_warm_fused_launches_changes_no_result(rt, name, B, monkeypatch):
+    """A warm-started fused launch takes the instances in the order of their previous solve's passes, longest first
+    (k_order); RMPC_NO_ORDER=1 keeps the index order.  Which slot an instance runs in -- and which instance shares
+    its wavefront -- must not change a bit of what it computes."""
+    sc = rt["make_scenario"](name, B=B, seed=3)
+    monkeypatch.delenv("RMPC_NO_ORDER", raising=False)
+    a = rt["Solver"](sc.desc, max_batch=B); a.set_warm_start(True)
+    monkeypatch.setenv("RMPC_NO_ORDER", "1")     # (read once, at rmpc_create)
+    b = rt["Solver"](sc.desc, max_batch=B); b.set_warm_start(True)
+    nx = sc.desc["nx"]
+    x = sc.xinit.copy(); x0 = sc.x0.copy()
+    for t in range(4):
+        ra = a.solve(x, x0, sc.params); rb = b.solve(x, x0, sc.params)
+        assert np.array_equal(ra["exitflag"], rb["exitflag"]) and np.array_equal(ra["iters"], rb["iters"]), t
+        assert np.array_equal(ra["z"], rb["z"]), t
+        assert a.last_passes() == b.last_passes()
+        ok = ra["exitflag"] >= 0
+        z = ra["z"]
+        x0 = np.where(ok[:, None, None], np.concatenate([z[:, 1:], z[:, -1:]], axis=1), x0)
+        x = np.where(ok[:, None], z[:, 1, :nx], x)
+    a.close(); b.close()
