@@ -218,6 +218,24 @@ __global__ __launch_bounds__(256) void k_unpack(Ws W, double *__restrict__ zout,
 
 // Multipliers of the finished solve -> the warm-start arrays of the batch's workspace D (W may be the compact
 // workspace: column b then belongs to instance orig[b]).  One lane per (column, stage).
+// d[j * ds] = s[j * ss], j < cnt, eight requests in flight (source and destination never alias: the copies below are
+// chains of dependent latencies otherwise -- 50 us for the arm's multipliers, 105 us for a migration of 128 instances)
+__device__ __forceinline__ void copy_strided(double *__restrict__ d, const double *__restrict__ s, const int cnt, const size_t ds,
+                                             const size_t ss) {
+  int j = 0;
+  for (; j + 8 <= cnt; j += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = s[(size_t)(j + u) * ss];
+#pragma unroll
+    for (int u = 0; u < 8; u++) d[(size_t)(j + u) * ds] = v[u];
+  }
+  for (; j < cnt; j++) d[(size_t)j * ds] = s[(size_t)j * ss];
+}
+__device__ __forceinline__ void fill_strided(double *__restrict__ d, const double val, const int cnt, const size_t ds) {
+  for (int j = 0; j < cnt; j++) d[(size_t)j * ds] = val;
+}
+
 __global__ __launch_bounds__(256) void k_save_duals(const Ws W, const Ws D, int B, int m, int nx, const int *__restrict__ orig,
                                                     double mu0) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
@@ -230,8 +248,15 @@ __global__ __launch_bounds__(256) void k_save_duals(const Ws W, const Ws D, int 
   const int st = W.status[b];
   const double mu = W.mu[b];
   const bool ok = (st == ST_ACTIVE || st >= 0) && isfinite(mu) && mu > 0.0;
-  for (int i = 0; i < m; i++) D.wlam[((size_t)i * D.N + k) * D.Bp + ob] = ok ? W.lam[cur][IDX(i, k, b)] : 0.0;
-  for (int j = 0; j < nx; j++) D.wnu[((size_t)j * D.N + k) * D.Bp + ob] = ok ? W.nu[cur][IDX(j, k, b)] : 0.0;
+  double *const dl = D.wlam + (size_t)k * D.Bp + ob, *const dn = D.wnu + (size_t)k * D.Bp + ob;
+  const size_t ds = (size_t)D.N * D.Bp, ss = (size_t)W.N * W.Bp;
+  if (ok) {
+    copy_strided(dl, W.lam[cur] + (size_t)k * W.Bp + b, m, ds, ss);
+    copy_strided(dn, W.nu[cur] + (size_t)k * W.Bp + b, nx, ds, ss);
+  } else {
+    fill_strided(dl, 0.0, m, ds);
+    fill_strided(dn, 0.0, nx, ds);
+  }
   if (k == 0) D.wmu[ob] = ok ? mu : mu0;
 }
 
@@ -283,15 +308,18 @@ __global__ __launch_bounds__(64) void k_migrate(const Ws S, const Ws D, int n, i
   const int cur = S.cur[b];
   auto si = [&](int slot) { return ((size_t)slot * S.N + k) * S.Bp + b; };
   auto di = [&](int slot) { return ((size_t)slot * D.N + k) * D.Bp + li; };
-  for (int j = 0; j < nv; j++) { D.z[0][di(j)] = S.z[cur][si(j)]; D.dz[di(j)] = S.dz[si(j)]; }
-  for (int i = 0; i < m; i++) {
-    D.t[0][di(i)] = S.t[cur][si(i)];
-    D.lam[0][di(i)] = S.lam[cur][si(i)];
+  {
+    const size_t ds = (size_t)D.N * D.Bp, ss = (size_t)S.N * S.Bp, d0 = di(0), s0 = si(0);
+    copy_strided(D.z[0] + d0, S.z[cur] + s0, nv, ds, ss);
+    copy_strided(D.dz + d0, S.dz + s0, nv, ds, ss);
+    copy_strided(D.t[0] + d0, S.t[cur] + s0, m, ds, ss);
+    copy_strided(D.lam[0] + d0, S.lam[cur] + s0, m, ds, ss);
+    copy_strided(D.grow[0] + d0, S.grow[cur] + s0, nh, ds, ss);
+    copy_strided(D.Jq[0] + d0, S.Jq[cur] + s0, njq, ds, ss);
+    copy_strided(D.nu[0] + d0, S.nu[cur] + s0, nx, ds, ss);
+    copy_strided(D.nunew + d0, S.nunew + s0, nx, ds, ss);
+    copy_strided(D.p + d0, S.p + s0, npar, ds, ss);
   }
-  for (int i = 0; i < nh; i++) D.grow[0][di(i)] = S.grow[cur][si(i)];
-  for (int i = 0; i < njq; i++) D.Jq[0][di(i)] = S.Jq[cur][si(i)];
-  for (int j = 0; j < nx; j++) { D.nu[0][di(j)] = S.nu[cur][si(j)]; D.nunew[di(j)] = S.nunew[si(j)]; }
-  for (int j = 0; j < npar; j++) D.p[di(j)] = S.p[si(j)];
   D.gphi[di(0)] = S.gphi[si(0)];
   if (k == 0) {
     D.amin_p[li] = S.amin_p[b]; D.amin_d[li] = S.amin_d[b];
@@ -3056,42 +3084,48 @@ __global__ __launch_bounds__(256) void k_scene(const SceneDev S, const SceneOff 
 // Closed loop between two solves: the plant is the model's own ERK2 map applied to the first
 // control of the previous plan, the warm start is the shifted plan (shiftHorizon,
 // mpcPlanner.py:215-226) or the current state repeated (setX0 "current_state", :228-232).
+constexpr int kAdvanceIB = 16;   // instances per block of k_advance
 template <class C>
 __global__ __launch_bounds__(256) void k_advance(const DevModel M, const double *__restrict__ zprev, double *__restrict__ xinit,
                                                  double *__restrict__ x0, int B, int previous_plan_all,
                                                  const int *__restrict__ exitflag) {
-  constexpr int NX = C::NX, NS = C::NS, NV = C::NV;
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= B) return;
+  // A block takes kAdvanceIB instances: one lane each for the plant step, then all 256 lanes shift the plans
+  // element by element (contiguous in the ABI layout [b][k][j]: coalesced; one lane per instance walking its
+  // N x nvar plan took 76 us for 1024 arms).
+  constexpr int NX = C::NX, NS = C::NS, NV = C::NV, IB = kAdvanceIB;
+  __shared__ double sx[IB][NX];
+  __shared__ int spp[IB];
+  const int b0 = blockIdx.x * IB, t = threadIdx.x;
   const int N = M.N;
-  double z[NV], xn[NX];
+  if (t < IB && b0 + t < B) {
+    const int b = b0 + t;
+    double z[NV], xn[NX];
 #pragma unroll
-  for (int j = 0; j < NX; j++) z[j] = xinit[(size_t)b * NX + j];
+    for (int j = 0; j < NX; j++) z[j] = xinit[(size_t)b * NX + j];
 #pragma unroll
-  for (int j = NX; j < NV; j++) z[j] = zprev[(size_t)b * N * NV + j];  // slack and first control of the plan
-  if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
-    chain_step<C>(M.dt, z, xn);
-  } else {
-    double A5[25], B5[10];
-    diffdrive_step<C>(M.dt, z, xn, A5, B5, false);
-  }
-#pragma unroll
-  for (int j = 0; j < NX; j++) xinit[(size_t)b * NX + j] = xn[j];
-  // an instance whose last solve failed (exitflag < 0) has no plan worth shifting: it restarts from its state,
-  // as the boxer example of the reference does for its linearisation point (boxer_example.py:194-198)
-  const bool previous_plan = previous_plan_all && !(exitflag && exitflag[b] < 0);
-  for (int k = 0; k < N; k++) {
-    double *o = x0 + ((size_t)b * N + k) * NV;
-    if (previous_plan) {
-      const double *s = zprev + ((size_t)b * N + (k + 1 < N ? k + 1 : N - 1)) * NV;
-#pragma unroll
-      for (int j = 0; j < NV; j++) o[j] = s[j];
+    for (int j = NX; j < NV; j++) z[j] = zprev[(size_t)b * N * NV + j];  // slack and first control of the plan
+    if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
+      chain_step<C>(M.dt, z, xn);
     } else {
-#pragma unroll
-      for (int j = 0; j < NX; j++) o[j] = xn[j];
-#pragma unroll
-      for (int j = NX; j < NV; j++) o[j] = 0.0;
+      double A5[25], B5[10];
+      diffdrive_step<C>(M.dt, z, xn, A5, B5, false);
     }
+#pragma unroll
+    for (int j = 0; j < NX; j++) { xinit[(size_t)b * NX + j] = xn[j]; sx[t][j] = xn[j]; }
+    // an instance whose last solve failed (exitflag < 0) has no plan worth shifting: it restarts from its state,
+    // as the boxer example of the reference does for its linearisation point (boxer_example.py:194-198)
+    spp[t] = (previous_plan_all && !(exitflag && exitflag[b] < 0)) ? 1 : 0;
+  }
+  __syncthreads();
+  const int nb = (B - b0) < IB ? (B - b0) : IB;
+  const int per = N * NV;
+  for (int e = t; e < nb * per; e += 256) {
+    const int ib = e / per, r = e - ib * per, k = r / NV, j = r - k * NV;
+    const size_t base = (size_t)(b0 + ib) * per;
+    double val;
+    if (spp[ib]) val = zprev[base + (size_t)(k + 1 < N ? k + 1 : N - 1) * NV + j];
+    else val = j < NX ? sx[ib][j] : 0.0;
+    x0[base + r] = val;
   }
   (void)NS;
 }
@@ -4149,7 +4183,7 @@ int rmpc_advance_device_flags(rmpc_handle *h, int B, const double *d_z_prev, con
   if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;   // NULL: the legacy null stream, ordered with the caller's default-stream work
-  const dim3 g((B + 255) / 256), t(256);
+  const dim3 g((B + kAdvanceIB - 1) / kAdvanceIB), t(256);
   const int *ef = (const int *)d_exitflag;
   switch (h->variant) {
     case 0: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan, ef); break;

@@ -173,7 +173,8 @@ struct Cfg {
   // wavefront of another batch's k_riccati (96 VGPRs) can run beside it: -13 % throughput with four batches in flight
   static constexpr int SWEEP_WPE = 1;
   // k_riccati: no register cap (94 VGPRs for the point robot) -- at 80 the recursion spills inside its stage
-  // loop: -3 % throughput on cfg2, -20 % on cfg3 (measured)
+  // loop: -3 % throughput on cfg2, -20 % on cfg3 (measured); the arm at two wavefronts per SIMD (256 registers,
+  // 380 B scratch): 84 -> 154 us per launch of 1024 instances
   static constexpr int RIC_WPE = 1;
   // lanes per instance in the grouped Riccati blocks: half a wavefront for the small models
   static constexpr int RIC_LPI = (NX + NS_ + NU <= 16) ? 32 : 64;
