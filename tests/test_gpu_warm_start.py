@@ -106,9 +106,10 @@ def test_mixed_fleet_shard_closed_loop(rt):
                 assert (c1 + c2) >= 0.95 * B, (step, name, c1, c2, c0)
             iters[name].append(itmean)
     for name, it in iters.items():
-        # the warm start pays for the point robot and the boxer (about half the iterations); the arm's iterations
-        # are dominated by its Gauss-Newton tail, not by the barrier path
-        assert np.mean(it[2:]) < (0.8 if name != "cfg4" else 1.25) * it[0], (name, it[0], np.mean(it[2:]))
+        # the warm start pays: about half the iterations for the point robot and the boxer, and -- with the second
+        # derivatives of its kinematics in the curvature terms -- less than half for the arm (Gauss-Newton blocks alone
+        # left it crawling to the acceptable-termination test: more iterations warm than cold)
+        assert np.mean(it[2:]) < (0.8 if name != "cfg4" else 0.6) * it[0], (name, it[0], np.mean(it[2:]))
     # last step against the oracle started from the same state, plan and (device) multipliers is not possible
     # without exporting the multipliers; instead: the oracle, cold-started from the same state and shifted plan,
     # reaches the same plan (same NLP, same basin) within the solver tolerances on a sample
@@ -129,6 +130,34 @@ def test_mixed_fleet_shard_closed_loop(rt):
                 same += du <= 1e-3 * max(1.0, np.abs(r["z"][0, nxs:]).max())
         # (the NLP is non-convex: a cold and a warm start may settle in different local solutions for a few instances)
         assert tried >= 8 and same >= 0.75 * tried, (f["name"], tried, same)
+    shard.close()
+
+
+def test_mixed_fleet_real_time_settings(rt):
+    """The loop as `bench.py --config cfg5` runs it: iteration limit 20, acceptable-termination window 3, deadline of
+    24 passes per solve (40 for the boxers, rmpc_set_pass_budget), one episode of 40 control steps on a scaled-down
+    shard.  Bars: usable plans (exit flag 1 or 2) for >= 95 % of every robot type over the episode and >= 90 % in
+    every control step, the arms converged (flag 1, not merely acceptable) for >= 90 %, the pass kernels inside
+    their budget."""
+    import torch
+    from robot_mpcs_amd import fleet
+    counts = {"cfg2": 512, "cfg3": 384, "cfg4": 128}
+    shard = fleet.MixedFleetShard(counts, torch.device("cuda:0"), seed=7, previous_plan=True, warm_duals=True,
+                                  options={"max_iter": 20, "acc_iters": 3}, pass_budget={"cfg2": 24, "cfg3": 40, "cfg4": 24})
+    usable = {k: [] for k in counts}
+    conv = []
+    for step in range(40):
+        shard.tick()
+        for name, (c1, c2, c0, neg, itmean) in shard.stats().items():
+            usable[name].append((c1 + c2) / counts[name])
+            if name == "cfg4":
+                conv.append(c1 / counts[name])
+        arm = [f for f in shard.fleets if f["name"] == "cfg4"][0]
+        assert arm["s"].last_passes() <= 24
+    for name, u in usable.items():
+        assert np.mean(u[1:]) >= 0.95, (name, np.mean(u[1:]))
+        assert np.min(u[1:]) >= 0.90, (name, np.min(u[1:]))
+    assert np.mean(conv[1:]) >= 0.90, np.mean(conv[1:])
     shard.close()
 
 
