@@ -155,6 +155,11 @@ int rmpc_set_warm_start(rmpc_handle *h, int mode);
  * control step of thousands.  Budgets below max_iter + 1 also bound the iterations. */
 int rmpc_set_pass_budget(rmpc_handle *h, int passes);
 
+/* 1 when the solves of this handle run as ONE launch that needs no look from the host (k_fused: point robot and
+ * diff-drive base, N <= 32) -- rmpc_solve_batch_device then only enqueues work on the stream and returns; 0 when they
+ * run as pass kernels, whose host loop reads a counter every few passes and returns when the batch is done. */
+int rmpc_is_fused(const rmpc_handle *h);
+
 /* Workspace size in bytes for a given descriptor / batch (no allocation). */
 int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch);
 

@@ -4226,6 +4226,8 @@ int rmpc_set_pass_budget(rmpc_handle *h, int passes) {
   return 0;
 }
 
+int rmpc_is_fused(const rmpc_handle *h) { return (h && h->fused) ? 1 : 0; }
+
 int rmpc_set_profiling(rmpc_handle *h, int enable) {
   if (!h) return fail("null handle");
   h->profiling = enable != 0;

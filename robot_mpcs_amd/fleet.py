@@ -153,15 +153,16 @@ class MixedFleetShard:
                               exitflag=f["ef"])
 
     def tick(self, sync: bool = True):
-        """One control step of the whole shard.  The fused kernel needs no host look, so the three blocks are
-        simply enqueued on their streams; blocks on the pass kernels (the arm) poll a counter and get a host
-        thread each."""
-        import threading
-        th = [threading.Thread(target=self._one, args=(f,)) for f in self.fleets]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
+        """One control step of the whole shard.  The fused kernel needs no host look: its blocks are simply enqueued
+        on their streams (solve + plant step); the blocks on the pass kernels (the arm) poll a counter from the host
+        and run last, on the calling thread, while the others are already in flight (one host thread per block, or the
+        boxers enqueued before the point robots: the same rate within 1 %)."""
+        for f in self.fleets:
+            if f["s"].is_fused():
+                self._one(f)
+        for f in self.fleets:
+            if not f["s"].is_fused():
+                self._one(f)
         if sync:
             self.torch.cuda.synchronize(self.dev)
 
