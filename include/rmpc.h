@@ -208,6 +208,15 @@ int rmpc_solve_batch_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene
                                   const double *d_x0, double *d_z_out, int32_t *d_exitflag, int32_t *d_iters,
                                   double *d_kkt_res, double *d_obj, void *stream);
 
+/* The two halves of rmpc_solve_batch_scene_device, for callers that drive several handles on several streams: the
+ * packing kernels of all of them can be enqueued before the first solve (a fused solve fills every SIMD for
+ * milliseconds; a small kernel enqueued behind it on another stream waits for a free slot first).
+ * rmpc_solve_batch_packed_device solves with the parameters rmpc_pack_scene_workspace left in the workspace (same
+ * handle, same B, same stream). */
+int rmpc_pack_scene_workspace(rmpc_handle *h, int B, const rmpc_scene *scene, void *stream);
+int rmpc_solve_batch_packed_device(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, double *d_z_out,
+                                   int32_t *d_exitflag, int32_t *d_iters, double *d_kkt_res, double *d_obj, void *stream);
+
 /* Closed loop between two solves, on the device: xinit <- Phi(xinit, u_1 of the previous plan)
  * with the model's own ERK2 map (the plant of the examples' env.step), and the warm start
  * x0 <- shifted plan (shiftHorizon, mpcPlanner.py:215-226) when previous_plan != 0, else the new

@@ -72,7 +72,7 @@ EXPORTED_SYMBOLS = [
     "rmpc_version", "rmpc_source_hash", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
     "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_warm_start", "rmpc_set_pass_budget", "rmpc_is_fused", "rmpc_set_profiling", "rmpc_get_profile",
     "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep", "rmpc_spec_source", "rmpc_spec_name", "rmpc_spec_for", "rmpc_debug_poison_lds",
-    "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_advance_device", "rmpc_advance_device_flags", "rmpc_free_space_device",
+    "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_pack_scene_workspace", "rmpc_solve_batch_packed_device", "rmpc_advance_device", "rmpc_advance_device_flags", "rmpc_free_space_device",
 ]
 
 _lib = None
@@ -176,6 +176,10 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_debug_fused_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
     L.rmpc_pack_scene_device.restype = C.c_int
     L.rmpc_pack_scene_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(RmpcScene), C.c_void_p, C.c_void_p]
+    L.rmpc_pack_scene_workspace.restype = C.c_int
+    L.rmpc_pack_scene_workspace.argtypes = [C.c_void_p, C.c_int, C.POINTER(RmpcScene), C.c_void_p]
+    L.rmpc_solve_batch_packed_device.restype = C.c_int
+    L.rmpc_solve_batch_packed_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
     L.rmpc_solve_batch_scene_device.restype = C.c_int
     L.rmpc_solve_batch_scene_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(RmpcScene)] + [C.c_void_p] * 8
     L.rmpc_advance_device.restype = C.c_int
@@ -372,6 +376,18 @@ class Solver:
         rc = self._L.rmpc_solve_batch_scene_device(self._h, int(B), C.byref(scene), ptr(xinit), ptr(x0), ptr(z_out),
                                                    ptr(exitflag), ptr(iters), ptr(kkt), ptr(obj), st)
         self._check(rc, "rmpc_solve_batch_scene_device")
+
+    def pack_scene_workspace(self, B, scene: RmpcScene, stream=None):
+        """first half of ``solve_scene_device``: the scene's parameters into the solver's workspace"""
+        rc = self._L.rmpc_pack_scene_workspace(self._h, int(B), C.byref(scene), _stream_arg(stream))
+        self._check(rc, "rmpc_pack_scene_workspace")
+
+    def solve_packed_device(self, B, xinit, x0, z_out, exitflag, iters, kkt, obj, stream=None):
+        """second half: solve with the parameters ``pack_scene_workspace`` left in the workspace"""
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        rc = self._L.rmpc_solve_batch_packed_device(self._h, int(B), ptr(xinit), ptr(x0), ptr(z_out), ptr(exitflag), ptr(iters),
+                                                    ptr(kkt), ptr(obj), _stream_arg(stream))
+        self._check(rc, "rmpc_solve_batch_packed_device")
 
     def advance_device(self, B, z_prev, xinit, x0, previous_plan: bool, stream=None, exitflag=None):
         """``exitflag`` (device int32 [B], optional): instances whose solve failed restart from their state."""

@@ -3225,6 +3225,7 @@ struct rmpc_handle {
   int variant = -1;
   int max_passes = 0;
   int pass_budget = 0;            // rmpc_set_pass_budget (0: none)
+  int packed_B = 0;               // batch size of the parameters rmpc_pack_scene_workspace left in the workspace
   void *ws_base = nullptr;
   size_t ws_bytes = 0;
   hipStream_t stream = nullptr;
@@ -3820,9 +3821,12 @@ static int launch_fused_t(rmpc_handle *h, int B, const double *d_xinit, const do
   if (h->F.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
   // closed loop: the previous solve of this batch tells which instances take long (k_fused: launch order)
   const int use_order = (warm && !h->env_no_order) ? 1 : 0;
-  if (use_order) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const int *)h->F.lastp, h->F.order, B);
   hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, V>), dim3((B + 1) / 2), dim3(64), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
                      d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm, use_order);
+  // the order of the NEXT warm-started launch, right behind this one (in front of it the little kernel would wait
+  // for a free SIMD whenever another handle's fused launch fills the chip: 130 us in the fleet loop)
+  if (h->warm_mode && !h->env_no_order)
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const int *)h->F.lastp, h->F.order, B);
   return 0;
 }
 static int launch_fused(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
@@ -3853,6 +3857,7 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
   HIPCHK(hipSetDevice(h->device));
   fill_lane_bytes(h, B);
   if (h->have_duals && h->duals_B != B) h->have_duals = false;   // multipliers of another batch: cold start
+  if (d_params) h->packed_B = 0;   // (the workspace parameters are about to be overwritten)
   if (h->fused) {
     // one launch: every wavefront carries its two instances from the first sweep to the plan
     int cap = max_passes_override > 0 ? max_passes_override : h->max_passes;
@@ -4157,11 +4162,8 @@ int rmpc_pack_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene, doubl
   return 0;
 }
 
-int rmpc_solve_batch_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene, const double *d_xinit,
-                                  const double *d_x0, double *d_z_out, int32_t *d_exitflag, int32_t *d_iters,
-                                  double *d_kkt_res, double *d_obj, void *stream) {
-  if (!h || !scene || !d_xinit || !d_x0 || !d_z_out || !d_exitflag || !d_iters || !d_kkt_res || !d_obj)
-    return fail("null argument");
+int rmpc_pack_scene_workspace(rmpc_handle *h, int B, const rmpc_scene *scene, void *stream) {
+  if (!h || !scene) return fail("null argument");
   if (scene->struct_size != (int)sizeof(rmpc_scene)) return fail("rmpc_scene size mismatch");
   if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
   HIPCHK(hipSetDevice(h->device));
@@ -4175,7 +4177,25 @@ int rmpc_solve_batch_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene
     const int lanes = h->Bp * h->M.N;
     hipLaunchKernelGGL((k_scene<1>), dim3((lanes + 255) / 256), dim3(256), 0, st, S, O, h->W.p, B, h->Bp);
   }
-  return solve_device(h, B, d_xinit, d_x0, nullptr, d_z_out, d_exitflag, d_iters, d_kkt_res, d_obj, st, 0);
+  HIPCHK(hipGetLastError());
+  h->packed_B = B;
+  return 0;
+}
+
+int rmpc_solve_batch_packed_device(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, double *d_z_out,
+                                   int32_t *d_exitflag, int32_t *d_iters, double *d_kkt_res, double *d_obj, void *stream) {
+  if (!h || !d_xinit || !d_x0 || !d_z_out || !d_exitflag || !d_iters || !d_kkt_res || !d_obj) return fail("null argument");
+  if (h->packed_B != B) return fail("no parameters of this batch size in the workspace (rmpc_pack_scene_workspace first)");
+  return solve_device(h, B, d_xinit, d_x0, nullptr, d_z_out, d_exitflag, d_iters, d_kkt_res, d_obj, (hipStream_t)stream, 0);
+}
+
+int rmpc_solve_batch_scene_device(rmpc_handle *h, int B, const rmpc_scene *scene, const double *d_xinit,
+                                  const double *d_x0, double *d_z_out, int32_t *d_exitflag, int32_t *d_iters,
+                                  double *d_kkt_res, double *d_obj, void *stream) {
+  if (!h || !scene || !d_xinit || !d_x0 || !d_z_out || !d_exitflag || !d_iters || !d_kkt_res || !d_obj)
+    return fail("null argument");
+  if (rmpc_pack_scene_workspace(h, B, scene, stream)) return -1;
+  return rmpc_solve_batch_packed_device(h, B, d_xinit, d_x0, d_z_out, d_exitflag, d_iters, d_kkt_res, d_obj, stream);
 }
 
 int rmpc_advance_device_flags(rmpc_handle *h, int B, const double *d_z_prev, const int32_t *d_exitflag, double *d_xinit,

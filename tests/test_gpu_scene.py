@@ -90,6 +90,16 @@ def test_fused_scene_solve_equals_plain_solve(rt, name, B):
     torch.cuda.synchronize()
     assert np.array_equal(z.cpu().numpy(), plain["z"]) and np.array_equal(ef.cpu().numpy(), plain["exitflag"])
     assert np.array_equal(it.cpu().numpy(), plain["iters"])
+    # the two halves of the scene solve, for callers that pack the scenes of several handles before the first solve
+    z2 = torch.full_like(z, float("nan")); ef2 = torch.zeros_like(ef); it2 = torch.zeros_like(it)
+    with pytest.raises(Exception):    # nothing packed for this batch size yet
+        s.solve(sc.xinit, sc.x0, sc.params)          # (a plain solve overwrites the workspace parameters)
+        s.solve_packed_device(B, tx, t0, z2, ef2, it2, kkt, obj)
+    s.pack_scene_workspace(B, scene)
+    s.solve_packed_device(B, tx, t0, z2, ef2, it2, kkt, obj)
+    torch.cuda.synchronize()
+    assert np.array_equal(z2.cpu().numpy(), plain["z"]) and np.array_equal(ef2.cpu().numpy(), plain["exitflag"])
+    assert np.array_equal(it2.cpu().numpy(), plain["iters"])
     s.close()
 
 
