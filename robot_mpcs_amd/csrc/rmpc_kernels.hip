@@ -430,8 +430,13 @@ struct SweepK { int N; double dt; int use_curv; };
 template <class C, int EARLY_MODE = -1, class RP = gdouble, class V = RtView, int FIRSTC = -1>
 __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const SweepIO<RP> &io, const int k,
                                            const bool first_rt, const bool nostep, const double alpha, const double adual,
-                                           const double mu, Partials &out) {
+                                           const double mu, Partials &out, ldouble *const qacc = nullptr) {
   const bool first = FIRSTC < 0 ? first_rt : (FIRSTC != 0);
+  // (FKCURV, k_sweep) the two 7 x 7 blocks of the q variables are accumulated in LDS, one column of 2 x 28 doubles per
+  // lane (qacc, lane stride kSweepBlock): they are touched once per FK point and by the joint-limit rows only, and the
+  // kernel has no register to spare for them
+  constexpr bool QLDS = C::FKCURV;
+  auto qtri = [](int a, int c) __attribute__((always_inline)) { return a * C::NQ - a * (a - 1) / 2 + (c - a); };
 #ifdef RMPC_STAMPS
   long long sw_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -551,6 +556,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
 #pragma unroll
     for (int j = 0; j < NX; j++) {
       xk1[j] = nostep ? x1[j] : x1[j] + al * dx1[j];
+      if constexpr (QLDS) qacc[(2 * C::NQ2 + j) * kSweepBlock] = xk1[j];   // (read back for the defect, at the end)
       double v = 0.0, w = 0.0;
       if (!first && k >= 1) v = nostep ? n0[j] : n0[j] + al * (n0n[j] - n0[j]);
       if (!first && k < N - 1) w = nostep ? n1[j] : n1[j] + al * (n1n[j] - n1[j]);
@@ -561,6 +567,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         if (k < N - 1) w = io.wn[(size_t)j * SS + loff2];
       }
       nuk[j] = v;
+      if constexpr (QLDS) { if (j < NQ) qacc[(2 * C::NQ2 + NX + (j < NQ ? j : 0)) * kSweepBlock] = v; }
       nun[j] = w;
       nn[IDXL(j)] = v;
     }
@@ -579,6 +586,10 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
   for (int a = 0; a < NQ; a++)
 #pragma unroll
     for (int c = 0; c < NQ; c++) Qqq[a][c] = 0;
+  if constexpr (QLDS) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2 * C::NQ2; s2++) qacc[s2 * kSweepBlock] = 0.0;
+  }
   double f = 0.0;
   int bad = 0;
   double theta = 0.0, rineq = 0.0, rcomp = 0.0, sumc = 0.0, minc = 1e300;
@@ -665,8 +676,10 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         f += on ? cN * ih : 0.0;
         gf[j] += on ? -cN * (ih * ih) * sg : 0.0;
         const double c2 = on ? 2.0 * cN * (ih * ih * ih) : 0.0;
-        if (j < NQ) Qqq[j < NQ ? j : 0][j < NQ ? j : 0] += c2;
-        else Dg[j] += c2;
+        if (j < NQ) {
+          if constexpr (QLDS) qacc[qtri(j < NQ ? j : 0, j < NQ ? j : 0) * kSweepBlock] += c2;
+          else Qqq[j < NQ ? j : 0][j < NQ ? j : 0] += c2;
+        } else Dg[j] += c2;
       }
       double g = h;
       if constexpr (NS > 0) { if (soft) g += sl; }
@@ -680,8 +693,10 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
       q0[j] += sg * rw.ca;
       q1[j] += sg * rw.cb;
       rs[j] -= sg * rw.lv;
-      if (j < NQ) Qqq[j < NQ ? j : 0][j < NQ ? j : 0] += rw.sig;
-      else Dg[j] += rw.sig;
+      if (j < NQ) {
+        if constexpr (QLDS) qacc[qtri(j < NQ ? j : 0, j < NQ ? j : 0) * kSweepBlock] += rw.sig;
+        else Qqq[j < NQ ? j : 0][j < NQ ? j : 0] += rw.sig;
+      } else Dg[j] += rw.sig;
       if constexpr (NS > 0) {
         if (soft) {
           cs[j] += rw.sig * sg;
@@ -709,7 +724,10 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
       }
     }
     if (!(j < NX && k == 0)) {   // x_1 is fixed: no stationarity condition
-      if constexpr (j < NX) r -= nuk[j];
+      if constexpr (j < NX) {
+        if constexpr (QLDS && j < NQ) r -= qacc[(2 * C::NQ2 + NX + j) * kSweepBlock];
+        else r -= nuk[j];
+      }
       rstat = fmax(rstat, fabs(r));
     }
     if constexpr (j >= NQ) rec[C::R_DG + j - NQ] = Dg[j];
@@ -945,7 +963,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
       for (int a = 0; a < NQ; a++) {
         const Vec3 u = symv(TQ, J[a]);
 #pragma unroll
-        for (int c = a; c < NQ; c++) Qqq[a][c] += dot(u, J[c]);
+        for (int c = a; c < NQ; c++) qacc[qtri(a, c) * kSweepBlock] += dot(u, J[c]);
       }
       if (M.use_curv) {
 #pragma unroll
@@ -957,7 +975,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
             w = {w.x + G.x, w.y + G.y, w.z + G.z};
           }
 #pragma unroll
-          for (int c = a; c < NQ; c++) Cqq[a][c] += dot(w, J[c]);
+          for (int c = a; c < NQ; c++) qacc[(C::NQ2 + qtri(a, c)) * kSweepBlock] += dot(w, J[c]);
         }
       }
     }
@@ -981,7 +999,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
       chain_step<C>(M.dt, z, xn);
 #pragma unroll
       for (int j = 0; j < NX; j++) {
-        const double r = xn[j] - xk1[j];
+        const double r = xn[j] - (QLDS ? (double)qacc[(2 * C::NQ2 + j) * kSweepBlock] : xk1[j]);
         rec[C::R_RC + j] = r;
         req = fmax(req, fabs(r));
         theta += fabs(r);
@@ -1070,7 +1088,11 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
 #pragma unroll
     for (int a = 0; a < NQ; a++)
 #pragma unroll
-      for (int c = a; c < NQ; c++) rec[C::R_Q + s++] = Qqq[a][c];
+      for (int c = a; c < NQ; c++) {
+        if constexpr (QLDS) rec[C::R_Q + s] = qacc[s * kSweepBlock];
+        else rec[C::R_Q + s] = Qqq[a][c];
+        s++;
+      }
   }
   {
     // (zero when the model or this solve does not use the curvature terms: k_riccati reads the slot regardless)
@@ -1078,7 +1100,11 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
 #pragma unroll
     for (int a = 0; a < NQ; a++)
 #pragma unroll
-      for (int c = a; c < NQ; c++) rec[C::R_C + s++] = (C::CURV && M.use_curv) ? Cqq[C::CURV ? a : 0][C::CURV ? c : 0] : 0.0;
+      for (int c = a; c < NQ; c++) {
+        if constexpr (QLDS) rec[C::R_C + s] = M.use_curv ? (double)qacc[(C::NQ2 + s) * kSweepBlock] : 0.0;
+        else rec[C::R_C + s] = (C::CURV && M.use_curv) ? Cqq[C::CURV ? a : 0][C::CURV ? c : 0] : 0.0;
+        s++;
+      }
   }
   rec[C::R_ZERO] = 0.0;
   const double logsum = log(lprod) + 0.6931471805599453094 * (double)lexp;
@@ -1128,8 +1154,10 @@ __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevMo
   Partials pt;
   const V v(M, *Tp);
   const SweepK sk = {M.N, M.dt, M.use_curv};
-  if (first) sweep_body<C, -1, gdouble, V, 1>(sk, v, io, k, true, nostep, alpha, adual, W.mu[b], pt);
-  else sweep_body<C, -1, gdouble, V, 0>(sk, v, io, k, false, nostep, alpha, adual, W.mu[b], pt);
+  __shared__ double sq[C::FKCURV ? (2 * C::NQ2 + C::NX + C::NQ) * kSweepBlock : 1];
+  ldouble *const qacc = (ldouble *)sq + threadIdx.x;
+  if (first) sweep_body<C, -1, gdouble, V, 1>(sk, v, io, k, true, nostep, alpha, adual, W.mu[b], pt, qacc);
+  else sweep_body<C, -1, gdouble, V, 0>(sk, v, io, k, false, nostep, alpha, adual, W.mu[b], pt, qacc);
   const unsigned loff = io.loff;
   const size_t SS = io.SS;
   W.part[IDXL(P_F)] = pt.f;
