@@ -506,3 +506,24 @@ def test_pass_budget_cuts_only_the_unfinished(rt, name, B, budget):
         o.solve(sc.xinit[b], sc.x0[b], sc.params[b])
         passes[b] = olib().orc_last_passes()
     assert ((passes <= budget) == done).mean() >= 0.9, (passes, done)
+
+
+def test_is_fused_tells_which_solves_need_no_host_look(rt, monkeypatch):
+    """rmpc_is_fused: the point robot and the diff-drive base (N <= 32) solve in one launch, the arm and long horizons
+    through the pass kernels; RMPC_NO_FUSED=1 (read at rmpc_create) sends everything through the pass kernels."""
+    monkeypatch.delenv("RMPC_NO_FUSED", raising=False)
+    want = {"cfg2": True, "cfg3": True, "cfg4": False}
+    for name, fused in want.items():
+        sc = rt["make_scenario"](name, B=4, seed=1)
+        s = rt["Solver"](sc.desc, max_batch=4)
+        assert s.is_fused() == fused, name
+        s.close()
+    sc = rt["make_scenario"]("cfg2", B=4, seed=1, time_horizon=40)
+    s = rt["Solver"](sc.desc, max_batch=4)
+    assert not s.is_fused()
+    s.close()
+    monkeypatch.setenv("RMPC_NO_FUSED", "1")
+    sc = rt["make_scenario"]("cfg2", B=4, seed=1)
+    s = rt["Solver"](sc.desc, max_batch=4)
+    assert not s.is_fused()
+    s.close()
