@@ -37,6 +37,14 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_VECTOR_TFLOPS = 78.6
+# what the counters (profiles/r0N_*_pmc.csv, *_phase_stamps.txt) show each kernel to be limited by; the HBM figures of
+# `roofline` are the nominal accounting of SURVEY.md 8(d), not the limiter
+BOUND_BY_COUNTERS = {
+    "k_fused": "latency (one wavefront per SIMD: fp64 dependency chains + LDS round trips of the recursion; iterate streamed through L2 / Infinity Cache)",
+    "k_sweep": "latency (memory requests at one wavefront per SIMD), then fp64 vector issue",
+    "k_riccati": "latency (LDS round trips, 7x7 factorisation chain)",
+    "k_step": "memory latency",
+}
 METRIC = "MPC solves/sec (batched) at N=30, pointRobot & panda; 1/2/4/8 MI355X"
 WORKLOADS = {
     "cfg1": "BASELINE configs[0]: pointRobot N=10, 1 instance",
@@ -133,11 +141,17 @@ class Leg:
         """one handle, one stream, HIP events around every kernel: exclusive per-kernel durations and the batch latency"""
         torch = self.torch
         sv = self.solvers[0]
-        torch.cuda.synchronize(self.dev)
-        t1 = time.perf_counter()
-        self._run(0, self.counter, 1)
-        torch.cuda.synchronize(self.dev)
-        latency_ms = 1e3 * (time.perf_counter() - t1)
+        # one call alone on an idle GPU, once per input set: SURVEY.md 8(d)'s "B / wall time of one rmpc_solve_batch"
+        lat = []
+        for j in range(len(self.inputs)):
+            torch.cuda.synchronize(self.dev)
+            t1 = time.perf_counter()
+            self._run(0, self.counter + j, 1)
+            torch.cuda.synchronize(self.dev)
+            lat.append(1e3 * (time.perf_counter() - t1))
+        self.counter += len(self.inputs) - 1
+        self.single_call_ms = lat
+        latency_ms = sum(lat) / len(lat)
         sv.set_profiling(True)
         t1 = time.perf_counter()
         self._run(0, self.counter + 1, nsteps)
@@ -191,7 +205,10 @@ def kernel_report(prof, wall_ms, nsteps, B, d, iters_mean):
         except Exception:
             traffic = None
     return {
-        "kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        # `bound`: the roofline `achieved` / `peak` / `frac` are priced against (the contract's HBM accounting of SURVEY.md
+        # 8(d)); `bound_by_counters`: what the PMC passes and the phase stamps under profiles/ say limits the kernel
+        "kernel": name, "bound": "hbm", "bound_by_counters": BOUND_BY_COUNTERS.get(name, "latency"),
+        "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches": int(v["launches"]),
         "exclusive_leg": {"steps": nsteps, "wall_ms": wall_ms, "kernel_ms_sum": sum(p["total_ms"] for p in kern.values()),
@@ -336,8 +353,29 @@ def run_cfg5(args, fleet, dev, rank, world, dd, fence, steps, warmup):
                 per_fleet=per)
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` typed without a launcher: start the N ranks the contract's launch line would start
+    (``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...``) as a child process, BEFORE this process
+    has touched a GPU, and leave with the child's exit code.  A plain run must never report ``n_gpus: 1`` for
+    ``--gpus 8``."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -345,7 +383,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         # No HIP device: there is no CPU fallback.  Under a multi-rank launch the rendezvous and the rank / argument
@@ -439,7 +477,8 @@ def main():
             lat, wall, pr = lo.exclusive(4) if not args.no_kernel_events else (None, None, None)
             d2 = dict(lo.d, _cfg=other)
             legs[other] = {"workload": WORKLOADS[other], "value": lo.B * world * k / el, "unit": "solves/s", "steps": k,
-                           "ms_per_step": 1e3 * el / k, "batch_latency_ms": lat, "solve_stats": st,
+                           "ms_per_step": 1e3 * el / k, "batch_latency_ms": lat,
+                           "value_single_call": (lo.B * world / (lat * 1e-3)) if lat else None, "solve_stats": st,
                            "roofline": kernel_report(pr, wall, 4, lo.B, d2, st["iters_mean"]) if pr else None}
             lo.close()
 
@@ -454,6 +493,12 @@ def main():
         stats = fleet.summarize(allstats, B)
         value = B * world * args.steps / elapsed_max
         out = dict(base, value=value, ms_per_step=1e3 * elapsed_max / args.steps, batch_latency_ms=latency_ms,
+                   # `value` is the pipelined rate of the timed region (S launches in flight); this is SURVEY.md 8(d)'s
+                   # definition, B / wall time of ONE call alone on the GPU (mean over the input sets), per GPU x world
+                   value_single_call=(B * world / (latency_ms * 1e-3)) if latency_ms else None,
+                   single_call_ms=getattr(leg, "single_call_ms", None),
+                   value_note=("value: %d solver handles on %d streams take the steps round robin (launches overlap); "
+                               "value_single_call: one rmpc_solve_batch_device at a time" % (S, S)),
                    config={"workload": WORKLOADS[cfg], "batch_per_gpu": B, "horizon": leg.N, "nvar": leg.nv,
                            "npar": d["npar"], "nh": d["nh"],
                            "warm_start": "current_state (cold multipliers, every step solves from scratch)",
@@ -479,6 +524,12 @@ def main():
                     rf["full_chip_launch"]["instances_per_launch"] = fb
                     rf["full_chip_launch"]["note"] = ("one launch of %d instances (= %d x the step's batch) alone on the GPU: the kernel with "
                                                       "every CU busy, as in the timed region where %d launches overlap" % (fb, S, S))
+                # flat copies (a consumer that keeps only the scalar keys of `roofline` still sees them)
+                rf["frac_fp64_vector"] = rf["solve_level"]["frac_fp64_vector"]
+                rf["frac_hbm_timed_region"] = rf["solve_level"]["frac_hbm"]
+                if full_chip:
+                    rf["full_chip_frac"] = rf["full_chip_launch"]["frac"]
+                    rf["full_chip_avg_launch_ms"] = rf["full_chip_launch"]["avg_launch_ms"]
                 out["roofline"] = rf
         if legs:
             out["legs"] = legs

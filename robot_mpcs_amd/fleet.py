@@ -186,6 +186,7 @@ class MixedFleetShard:
         end up in states from which the NLP is infeasible -- a property of the task, not of the solver; a fleet gets
         new goals long before)."""
         for f in self.fleets:
+            # (x_start / x0_start were created on the default stream: __init__ synchronises the device behind them)
             with self.torch.cuda.stream(f["stream"]):
                 f["x"].copy_(f["x_start"]); f["x0"].copy_(f["x0_start"])
             f["s"].set_warm_start(self.warm_duals)   # (re-arming forgets the stored multipliers)
@@ -193,7 +194,11 @@ class MixedFleetShard:
     def stats(self):
         """per block: [converged, acceptable, iteration cap, failed, mean iterations] of the last control step"""
         out = {}
+        cur = self.torch.cuda.current_stream(self.dev)
         for f in self.fleets:
+            # the flags are written by kernels on the block's own stream: order the reads below behind them (after
+            # tick(sync=False) nothing else does)
+            cur.wait_stream(f["stream"])
             ef = f["ef"]
             out[f["name"]] = [int((ef == 1).sum()), int((ef == 2).sum()), int((ef == 0).sum()), int((ef < 0).sum()),
                               float(f["it"].float().mean())]

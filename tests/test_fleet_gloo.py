@@ -145,3 +145,29 @@ def test_bench_launch_line_plumbing_without_a_device(tmp_path):
     d = json.loads(line[-1])
     assert "HIP device" in d["error"] and d["world_size"] == 2
     assert sorted(x["rank"] for x in d["ranks"]) == [0, 1] and all(x["gpus"] == 2 and x["steps"] == 3 for x in d["ranks"])
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks(tmp_path):
+    """``python bench.py --gpus 2`` typed without torch.distributed.run: the program starts the two ranks itself (before
+    it touches a GPU) instead of measuring one GPU and printing ``n_gpus: 1``; ``--gpus`` that contradicts WORLD_SIZE is
+    refused."""
+    import json
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert line, r.stdout + r.stderr
+    d = json.loads(line[-1])
+    assert d["world_size"] == 2 and sorted(x["rank"] for x in d["ranks"]) == [0, 1]
+    assert all(x["gpus"] == 2 for x in d["ranks"])
+    # a launcher's WORLD_SIZE that contradicts --gpus is an error, also for --gpus 1
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
+                        timeout=120, cwd=ROOT, env=env2)
+    assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)

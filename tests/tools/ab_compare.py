@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Comparison of two scripts/ab_dump.py outputs: exit flags and iteration counts must be identical, floating-point
+"""Comparison of two tests/tools/ab_dump.py outputs: exit flags and iteration counts must be identical, floating-point
 results bitwise identical or (with --tol T) within T -- the fast in-LDS recursion of the fused kernel contracts its
 multiply-adds differently from the pass kernels' generic path, a rounding-level difference."""
 import sys

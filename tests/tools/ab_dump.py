@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Development aid: solve seeded batches with the library named by RMPC_LIB_PATH and dump the raw results, so that
-two builds can be compared bit for bit (scripts/ab_compare.py)."""
+two builds can be compared bit for bit (tests/tools/ab_compare.py)."""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from robot_mpcs_amd._lib import Solver  # noqa: E402
 from robot_mpcs_amd.scenarios import make_scenario  # noqa: E402

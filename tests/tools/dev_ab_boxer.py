@@ -2,7 +2,7 @@
 """Development aid: boxer configurations through the fused kernel and through the pass kernels (RMPC_NO_FUSED), compared."""
 import os, sys, subprocess, json
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 1 and sys.argv[1] == "dump":
     from robot_mpcs_amd._lib import Solver
@@ -19,10 +19,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "dump":
     np.savez(sys.argv[2], **out)
 else:
     env = dict(os.environ)
-    subprocess.check_call([sys.executable, __file__, "dump", "/tmp/ab_fused.npz"], env=env)
+    subprocess.check_call([sys.executable, __file__, "dump", "gpurun_out/ab_fused.npz"], env=env)
     env["RMPC_NO_FUSED"] = "1"
-    subprocess.check_call([sys.executable, __file__, "dump", "/tmp/ab_pass.npz"], env=env)
-    a, b = np.load("/tmp/ab_fused.npz"), np.load("/tmp/ab_pass.npz")
+    subprocess.check_call([sys.executable, __file__, "dump", "gpurun_out/ab_pass.npz"], env=env)
+    a, b = np.load("gpurun_out/ab_fused.npz"), np.load("gpurun_out/ab_pass.npz")
     worst = 0.0
     for k in a.files:
         if a[k].dtype.kind == "i":

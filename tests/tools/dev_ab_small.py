@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from robot_mpcs_amd._lib import Solver  # noqa: E402
 from robot_mpcs_amd.scenarios import make_scenario  # noqa: E402

@@ -2,7 +2,7 @@
 """Development aid: the arm's block of the cfg5 shard alone (for rocprofv3 --kernel-trace --stats)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from robot_mpcs_amd import fleet

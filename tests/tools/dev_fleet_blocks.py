@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Development aid: control-step time of each block of the cfg5 shard alone and of the whole shard
-(python scripts/dev_fleet_blocks.py [max_iter] [acc_iters])."""
+(python tests/tools/dev_fleet_blocks.py [max_iter] [acc_iters])."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from robot_mpcs_amd import fleet

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Development aid: instances still iterating after each pass in warm control steps of one cfg5 block
-(RMPC_DUMP_HIST=1 python scripts/dev_fleet_hist.py [max_iter] [cfg] [B])."""
+(RMPC_DUMP_HIST=1 python tests/tools/dev_fleet_hist.py [max_iter] [cfg] [B])."""
 import os, sys
 os.environ["RMPC_DUMP_HIST"] = "1"
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from robot_mpcs_amd import fleet

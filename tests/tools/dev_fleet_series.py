@@ -2,7 +2,7 @@
 """Development aid: per control step time, passes and flag counts of one cfg5 block."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from robot_mpcs_amd import fleet

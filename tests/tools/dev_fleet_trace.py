@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development aid: a few control steps of the cfg5 shard at the real-time settings (for rocprofv3 --kernel-trace)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from robot_mpcs_amd import fleet

@@ -2,7 +2,7 @@
 """Development aid: solve one configuration a few times (fresh handle each time), print flag / iteration statistics."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from robot_mpcs_amd._lib import Solver
 from robot_mpcs_amd.scenarios import make_scenario

@@ -4,7 +4,7 @@ flags, iterations and final residuals, and with ORC_TRACE=1 the residuals of eve
     python tests/tools/dev_oracle_loop.py cfg4 4 25 [trace_step]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 from oracle.oracle import Oracle
 from robot_mpcs_amd.scenarios import make_scenario

@@ -2,7 +2,7 @@
 """Development aid (CPU, oracle): warm-started closed loop of B instances; lists the slow solves per control step."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 from oracle.oracle import Oracle
 from robot_mpcs_amd.scenarios import make_scenario

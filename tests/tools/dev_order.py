@@ -2,7 +2,7 @@
 """Development aid: warm closed loop with and without the longest-first launch order (RMPC_NO_ORDER): identical results."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from robot_mpcs_amd._lib import Solver
 from robot_mpcs_amd.scenarios import make_scenario

@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from robot_mpcs_amd._lib import Solver
 from robot_mpcs_amd.scenarios import make_scenario
 sc = make_scenario("cfg2", B=4096, seed=9)

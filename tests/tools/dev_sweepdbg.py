@@ -2,7 +2,7 @@
 """Development aid: first sweep of a configuration against the oracle's stage evaluation, field by field."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 from oracle.oracle import Oracle
 from robot_mpcs_amd._lib import Solver

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Development aid: time of one configuration's solve (device-resident, per-kernel profile of the pass kernels).
-    python scripts/dev_time.py cfg4 1024 [reps]"""
+    python tests/tools/dev_time.py cfg4 1024 [reps]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from robot_mpcs_amd._lib import Solver

@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from robot_mpcs_amd._lib import Solver
 from robot_mpcs_amd.scenarios import make_scenario
 for name, B, seed in [("cfg1", 1, 0), ("cfg2", 700, 1), ("cfg2", 700, 1), ("cfg1", 1, 0), ("cfg2", 4096, 9)]:

@@ -1,5 +1,5 @@
 import os, sys, time, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 from robot_mpcs_amd.scenarios import make_scenario
 from robot_mpcs_amd._lib import Solver
 from oracle.oracle import Oracle

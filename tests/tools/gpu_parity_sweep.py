@@ -1,6 +1,6 @@
 """Development aid: GPU vs oracle over several seeds and batch sizes (wider than the test-suite cases)."""
 import os, sys, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 from robot_mpcs_amd.scenarios import make_scenario
 from robot_mpcs_amd._lib import Solver
 from oracle.oracle import Oracle

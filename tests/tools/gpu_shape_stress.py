@@ -1,7 +1,7 @@
 """Development aid: GPU vs oracle over odd batch sizes and horizons (index logic of the pass kernels, the half-wave
 Riccati blocks and the survivor migration)."""
 import os, sys, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 from robot_mpcs_amd.scenarios import make_scenario
 from robot_mpcs_amd._lib import Solver
 from oracle.oracle import Oracle

@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from robot_mpcs_amd._lib import Solver  # noqa: E402
 from robot_mpcs_amd.scenarios import DEFAULT_BATCH, make_scenario  # noqa: E402
