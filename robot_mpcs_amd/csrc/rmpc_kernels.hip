@@ -2178,8 +2178,10 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
 #pragma unroll
       for (int j = 0; j < NX; j++) { dw += kr[j] * dx[j]; nup += pr[j] * dx[j]; }
       // step of the stage: lanes < NW hold dw (slots NX..), the next NX lanes dx (slots 0..); nu+ for k >= 1
-      if (lane < NW + NX) so.dz[(size_t)(lane < NW ? NX + lane : lane - NW) * so.SS + (size_t)k * so.KS] = lane < NW ? dw : dxo;
-      if (isn && k >= 1) so.nunew[(size_t)in * so.SS + (size_t)k * so.KS] = nup;
+      // (the step lives in the slots: its strides are constants -- with the run-time strides of StepOut the address
+      //  arithmetic was 82 of the 176 instructions of a forward stage)
+      if (lane < NW + NX) so.dz[(lane < NW ? NX + lane : lane - NW) + k * GS] = lane < NW ? dw : dxo;
+      if (isn && k >= 1) so.nunew[in + k * GS] = nup;
       if (k < N - 1 && lane < NX) {
         double sx = rcv;
         sx += dxme;
@@ -2579,7 +2581,7 @@ struct FusedWs {
   double *wlam, *wnu, *wmu;       // [B][m][32], [B][nx][32], [B]: multipliers of the last solve (warm start)
   double *R;                      // [B][N][rs]   (models whose records do not fit LDS)
   double *KP;                     // [B][N][kps]
-  int *passes;                    // [1] most passes any instance of the last launch needed
+  int *passes;                    // [0] most passes any instance of the last launch needed, [1] the launch's queue counter
   int *lastp;                     // [B] passes of every instance in the last launch
   int *order;                     // [B] launch order of the next warm-started launch: instances by lastp, longest first
   long long *stamps;              // [blocks][8] cycles per phase (builds with -DRMPC_STAMPS only; development aid)
@@ -2766,14 +2768,12 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
   const V v(M, *Tp);
   const int half = threadIdx.x / LPI;
   const int k = threadIdx.x & (LPI - 1);       // stage of this lane; also its lane index inside the instance
-  // Workgroups are dispatched in index order and every SIMD holds one of these wavefronts for its whole solve: the
-  // launch ends with the wavefronts that started last.  In a closed loop (use_order) the instances are taken in the
-  // order of their previous solve's passes, longest first (k_order), so that the long solves start first and pair up;
-  // the arithmetic of an instance does not depend on its slot.
-  const int slot = blockIdx.x * IPW + half;
-  const bool valid = slot < B;
-  const int bi = valid ? (use_order ? F.order[slot] : slot) : B - 1;
-  const size_t b = bi;                          // (!valid: clamped -- addresses stay legal, nothing is written)
+  // The launch is a queue of instances, not a grid of pairs: a half-wavefront takes instance after instance until the
+  // queue is empty (its first one by its position in the grid, the following ones from an atomic counter), so a
+  // finished instance never holds its 32 lanes until its partner has finished too, and the grid is no larger than the
+  // chip.  In a closed loop (use_order) the queue holds the instances in the order of their previous solve's passes,
+  // longest first (k_order): longest-processing-time-first scheduling.  The arithmetic of an instance depends neither
+  // on its position in the queue nor on its partner.
   const int N = M.N;
   const bool stage = k < N;
 
@@ -2790,27 +2790,6 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
   const size_t S = kFusedStages;
   // the solver words of the two instances are parked here around the phase calls (the callees own the register file)
   __shared__ Inst sinst[IPW];
-  __shared__ int spass[IPW];     // passes in which the instance was still iterating
-  if (k == 0) spass[half] = 0;
-  // ---- prologue: ABI rows of this stage -> the instance's block (x_1 := xinit, mpcModel.py:108) -------
-  const FusedPtrs P0 = fused_ptrs(F, b);
-  if (valid && stage) {
-    const double *zr = x0 + (b * N + k) * NV;
-#pragma unroll
-    for (int j = 0; j < NV; j++) {
-      double v = zr[j];
-      if (k == 0 && j < NX) v = xinit[b * NX + j];
-      P0.pz[0][j * S + k] = v;
-    }
-    if constexpr (REC_LDS) {   // the step slots are read (and discarded) by the first sweep: keep them finite
-#pragma unroll
-      for (int j = 0; j < NV + NX; j++) slots[k * GS + DZ_OFF + j] = 0.0;
-    }
-    if (params) {
-      const double *pr = params + (b * N + k) * M.npar;
-      for (int j = 0; j < M.npar; j++) P0.pp[j * S + k] = pr[j];
-    }
-  }
   Inst s;
   const bool warm = warm_mode != 0;
   // (every lane of an instance holds the same words: its lane 0 parks them, all lanes take them back)
@@ -2818,26 +2797,113 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
   // (lane 0's store and the other lanes' loads are ordered by the wavefront fence: without it the compiler may
   //  keep a lane's copy from the previous unpark -- nothing in that lane's own program wrote the words since)
   auto unpark = [&]() __attribute__((always_inline)) { WSYNC(); s = sinst[half]; };
-  inst_init(s, warm ? warm_mu(F.wmu[b], M.mu0) : M.mu0);
-  if (!valid) s.status = 0;
+  inst_init(s, M.mu0);
+  s.status = 0;                 // (no instance yet)
+  size_t b = (size_t)(B - 1);   // instance of this half (none: clamped -- addresses stay legal, nothing is written)
+  bool valid = false;           // the half holds an instance
+  bool retired = false;         // the queue was empty when the half asked: it stays idle
+  bool first = true;            // the instance's next pass is its first
+  int ipass = 0;                // passes of the instance so far
+  int nextslot = blockIdx.x * IPW + half;   // queue position of the half's first instance (-1: ask the counter)
+  int *const qhead = F.passes + 1;          // positions handed out beyond the grid's own (zeroed before the launch)
   double gphi_sum = 0.0;   // merit slope of the current step (sum over the stages; step phase)
-  GSYNC();
 
 #ifdef RMPC_STAMPS
   long long st_sweep = 0, st_dec = 0, st_ric = 0, st_step = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
   long long st_sw[4] = {0, 0, 0, 0};
+  int st_ipass = 0;   // instance passes of this wavefront (both halves)
 #define STAMP_A() st_a = __builtin_amdgcn_s_memtime()
 #define STAMP_B(acc) do { st_b = __builtin_amdgcn_s_memtime(); acc += st_b - st_a; st_a = st_b; } while (0)
 #else
 #define STAMP_A()
 #define STAMP_B(acc)
 #endif
-  int pass = 0;
-  for (; pass < max_passes; pass++) {
-    const bool act = (s.status == ST_ACTIVE);
-    if (__ballot(act) == 0ull) break;
-    if (act && k == 0) spass[half]++;
-    const bool first = (pass == 0);
+  int pass = 0;   // passes of the wavefront
+  for (;; pass++) {
+    // ---- finished instances leave, idle halves take the next instance of the queue -----------------------------------
+    {
+      const bool over = valid && (s.status == ST_ACTIVE) && ipass >= max_passes;   // deadline (rmpc_set_pass_budget) or cap
+      const bool done = valid && (s.status != ST_ACTIVE || over);
+      if (__ballot(done || (!valid && !retired)) != 0ull) {
+        if (done) {
+          // epilogue: plan in the ABI layout, statistics (the trial point and the step were made visible to the whole
+          // wavefront by the ordering points of the pass that ended the solve)
+          const FusedPtrs Pe = fused_ptrs(F, b);
+          if (stage) {
+            const gdouble *zf = Pe.pz[s.cur];
+            double *zr = zout + (b * N + k) * NV;
+#pragma unroll
+            for (int j = 0; j < NV; j++) zr[j] = zf[j * S + k];
+            // multipliers for a warm start of the next solve of this instance (a failed solve leaves zeros and mu0)
+            const bool okd = (s.status == ST_ACTIVE || s.status >= 0) && isfinite(s.mu) && s.mu > 0.0;
+            const gdouble *lf = Pe.pl[s.cur], *nf = Pe.pn[s.cur];
+            for (int i = 0; i < F.m; i++) Pe.pwl[i * S + k] = okd ? lf[i * S + k] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; j++) Pe.pwn[j * S + k] = okd ? nf[j * S + k] : 0.0;
+          }
+          if (k == 0) {
+            exitflag[b] = (s.status == ST_ACTIVE) ? 0 : s.status;
+            iters_out[b] = s.iters;
+            kkt[b] = fmax(fmax(s.res_stat, s.res_eq), fmax(s.res_ineq, s.res_comp));
+            obj[b] = s.obj;
+            F.wmu[b] = ((s.status == ST_ACTIVE || s.status >= 0) && isfinite(s.mu) && s.mu > 0.0) ? s.mu : M.mu0;
+            F.lastp[b] = ipass;
+            atomicMax(F.passes, ipass);
+          }
+          valid = false;
+          s.status = 0;
+        }
+        if (!valid && !retired) {
+          int pos = nextslot;
+          nextslot = -1;
+          if (pos < 0) {
+            int t = 0;
+            if (k == 0) t = atomicAdd(qhead, 1);
+            pos = (int)gridDim.x * IPW + __shfl(t, half * LPI, 64);
+          }
+          if (pos < B) {
+            b = (size_t)(use_order ? F.order[pos] : pos);
+            valid = true;
+            // prologue: ABI rows of this stage -> the instance's block (x_1 := xinit, mpcModel.py:108)
+            const FusedPtrs P0 = fused_ptrs(F, b);
+            if (stage) {
+              const double *zr = x0 + (b * N + k) * NV;
+#pragma unroll
+              for (int j = 0; j < NV; j++) {
+                double v = zr[j];
+                if (k == 0 && j < NX) v = xinit[b * NX + j];
+                P0.pz[0][j * S + k] = v;
+              }
+              if constexpr (REC_LDS) {   // the step slots are read (and discarded) by the first sweep: keep them finite
+#pragma unroll
+                for (int j = 0; j < NV + NX; j++) slots[k * GS + DZ_OFF + j] = 0.0;
+              }
+              if (params) {
+                const double *pr = params + (b * N + k) * M.npar;
+                for (int j = 0; j < M.npar; j++) P0.pp[j * S + k] = pr[j];
+              }
+            }
+            inst_init(s, warm ? warm_mu(F.wmu[b], M.mu0) : M.mu0);
+            first = true;
+            ipass = 0;
+            gphi_sum = 0.0;
+          } else {
+            retired = true;
+            b = (size_t)(B - 1);
+          }
+        }
+        GSYNC();   // the new instance's block is complete before any lane reads another lane's part
+      }
+    }
+    const bool act = valid && (s.status == ST_ACTIVE);
+    if (__ballot(act) == 0ull) break;   // both halves are idle and the queue is empty
+    if (act) ipass++;
+#ifdef RMPC_STAMPS
+    st_ipass += __popcll(__ballot(act && k == 0));
+#endif
+    // which copy of the sweep the lane runs this pass (first pass of its instance or not): the two halves of the
+    // wavefront may differ (both copies then run, one after the other); an idle half follows its partner
+    const bool v1 = act ? first : (__ballot(act && first) != 0ull);
     STAMP_A();
     // ---- sweep: trial point, model functions, condensing, stage partials -------------------------------
     Partials q = {0, 0, 0, 0, 0, 0, 0, 0, 1e300, 0};
@@ -2854,7 +2920,7 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
       const bool nostep = first || (s.redo != 0);
       fresh = act && !nostep && (s.newstep != 0);
       const FusedWs *const Fp = (const FusedWs *)(Tp + 1);
-      if (first) ssr = fused_sweep_step_call<C, V, 1>(Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, act && stage, nostep, fresh, s.ls, s.amin_p, s.amin_d, gphi_sum, s.mu, warm ? 1 : 0);
+      if (v1) ssr = fused_sweep_step_call<C, V, 1>(Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, act && stage, nostep, fresh, s.ls, s.amin_p, s.amin_d, gphi_sum, s.mu, warm ? 1 : 0);
       else ssr = fused_sweep_step_call<C, V, 0>(Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, act && stage, nostep, fresh, s.ls, s.amin_p, s.amin_d, gphi_sum, s.mu, warm ? 1 : 0);
       q = ssr.q;
     } else if constexpr (V::SPEC) {
@@ -2919,6 +2985,7 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
     bool usec = false;
     bool recurse = false;
     if (act) recurse = inst_decide<C>(M, s, r, first, usec);
+    if (act) first = false;
     STAMP_B(st_dec);
     park();
     const double mu_r = s.mu;
@@ -2981,33 +3048,9 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
       for (int i = 0; i < 4; i++) o2[i] = st_sw[i];
     }
     o[0] = st_sweep; o[1] = st_dec; o[2] = st_ric; o[3] = st_step; o[4] = __builtin_amdgcn_s_memtime() - st_t0; o[5] = pass;
-    o[6] = st_t0;
+    o[6] = st_t0; o[7] = st_ipass;
   }
 #endif
-  // ---- epilogue: plan in the ABI layout, statistics ------------------------------------------------------
-  GSYNC();
-  const FusedPtrs Pe = fused_ptrs(F, b);
-  if (valid && stage) {
-    const gdouble *zf = Pe.pz[s.cur];
-    double *zr = zout + (b * N + k) * NV;
-#pragma unroll
-    for (int j = 0; j < NV; j++) zr[j] = zf[j * S + k];
-    // multipliers for a warm start of the next solve of this instance (a failed solve leaves zeros and mu0)
-    const bool okd = (s.status == ST_ACTIVE || s.status >= 0) && isfinite(s.mu) && s.mu > 0.0;
-    const gdouble *lf = Pe.pl[s.cur], *nf = Pe.pn[s.cur];
-    for (int i = 0; i < F.m; i++) Pe.pwl[i * S + k] = okd ? lf[i * S + k] : 0.0;
-#pragma unroll
-    for (int j = 0; j < NX; j++) Pe.pwn[j * S + k] = okd ? nf[j * S + k] : 0.0;
-  }
-  if (valid && k == 0) {
-    exitflag[b] = (s.status == ST_ACTIVE) ? 0 : s.status;
-    iters_out[b] = s.iters;
-    kkt[b] = fmax(fmax(s.res_stat, s.res_eq), fmax(s.res_ineq, s.res_comp));
-    obj[b] = s.obj;
-    F.wmu[b] = ((s.status == ST_ACTIVE || s.status >= 0) && isfinite(s.mu) && s.mu > 0.0) ? s.mu : M.mu0;
-    F.lastp[b] = spass[half];
-  }
-  if (threadIdx.x == 0) atomicMax(F.passes, pass);
 }
 
 // Launch order of a warm-started fused launch: the instances sorted by the passes of their previous solve, longest
@@ -3245,6 +3288,7 @@ struct rmpc_handle {
   int duals_B = 0;
   int spec = -1;        // generated view whose tables equal this descriptor's (rmpc_spec_gen.hpp), -1: runtime tables
   bool fused = false;   // this model runs the fused kernel (small models, N <= 32); the pass kernels otherwise
+  int fused_grid = 1024;  // wavefronts the chip holds at one per SIMD (4 x compute units): grid of a fused launch
   FusedWs F;
   int *h_passes = nullptr;  // pinned
   int device = 0;
@@ -3849,7 +3893,10 @@ static int launch_fused_t(rmpc_handle *h, int B, const double *d_xinit, const do
   if (h->F.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
   // closed loop: the previous solve of this batch tells which instances take long (k_fused: launch order)
   const int use_order = (warm && !h->env_no_order) ? 1 : 0;
-  hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, V>), dim3((B + 1) / 2), dim3(64), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
+  // the grid is the chip (one wavefront per SIMD: __launch_bounds__(64, 1)), the batch is a queue its halves drain
+  const int pairs = (B + 1) / 2;
+  const int grid = pairs < h->fused_grid ? pairs : h->fused_grid;
+  hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, V>), dim3(grid), dim3(64), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
                      d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm, use_order);
   // the order of the NEXT warm-started launch, right behind this one (in front of it the little kernel would wait
   // for a free SIMD whenever another handle's fused launch fills the chip: 130 us in the fleet loop)
@@ -3890,7 +3937,7 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
     // one launch: every wavefront carries its two instances from the first sweep to the plan
     int cap = max_passes_override > 0 ? max_passes_override : h->max_passes;
     if (h->pass_budget > 0 && h->pass_budget < cap) cap = h->pass_budget;
-    HIPCHK(hipMemsetAsync(h->F.passes, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(h->F.passes, 0, 16, st));   // [0] most passes of an instance, [1] queue counter
     {
       ProfScope ps(h, st, K_FUSED);
       if (launch_fused(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap)) return -1;
@@ -4061,6 +4108,11 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { delete h; return fail("no HIP device available"); }
   if (desc->device < 0 || desc->device >= ndev) { delete h; return fail("device ordinal out of range"); }
   h->device = desc->device;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->fused_grid = 4 * cus;
+    if (const char *g = getenv("RMPC_FUSED_GRID")) { const int v = atoi(g); if (v > 0) h->fused_grid = v; }   // (development switch)
+  }
   h->max_batch = max_batch;
   h->Bp = (max_batch + 63) / 64 * 64;
   h->max_passes = passes_cap(h->M);
