@@ -160,6 +160,14 @@ int rmpc_set_pass_budget(rmpc_handle *h, int passes);
  * run as pass kernels, whose host loop reads a counter every few passes and returns when the batch is done. */
 int rmpc_is_fused(const rmpc_handle *h);
 
+/* 1 when rmpc_solve_batch_device (and the scene / packed variants) of this handle only ENQUEUES work on the stream and
+ * returns -- no look from the host, the solve is ordered with the caller's stream like any kernel: fused handles
+ * always, handles on the pass kernels (the arm, N > 32) when a pass budget is set (the budgeted passes are enqueued
+ * whole; kernels leave at once when no instance iterates any more).  Without a budget the pass kernels' host loop
+ * reads a counter every few passes, because only it can know how many passes to enqueue (a solve then returns when
+ * the batch is done; the reference's solver.solve() is synchronous too, mpcPlanner.py:262). */
+int rmpc_is_async(const rmpc_handle *h);
+
 /* Workspace size in bytes for a given descriptor / batch (no allocation). */
 int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch);
 

@@ -70,7 +70,7 @@ class RmpcScene(C.Structure):
 # every symbol include/rmpc.h declares
 EXPORTED_SYMBOLS = [
     "rmpc_version", "rmpc_source_hash", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
-    "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_warm_start", "rmpc_set_pass_budget", "rmpc_is_fused", "rmpc_set_profiling", "rmpc_get_profile",
+    "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_warm_start", "rmpc_set_pass_budget", "rmpc_is_fused", "rmpc_is_async", "rmpc_set_profiling", "rmpc_get_profile",
     "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep", "rmpc_spec_source", "rmpc_spec_name", "rmpc_spec_for", "rmpc_debug_poison_lds",
     "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_pack_scene_workspace", "rmpc_solve_batch_packed_device", "rmpc_advance_device", "rmpc_advance_device_flags", "rmpc_free_space_device",
 ]
@@ -160,6 +160,8 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_set_pass_budget.argtypes = [C.c_void_p, C.c_int]
     L.rmpc_is_fused.restype = C.c_int
     L.rmpc_is_fused.argtypes = [C.c_void_p]
+    L.rmpc_is_async.restype = C.c_int
+    L.rmpc_is_async.argtypes = [C.c_void_p]
     L.rmpc_last_passes.restype = C.c_int
     L.rmpc_last_passes.argtypes = [C.c_void_p]
     L.rmpc_debug_sweep.restype = C.c_int
@@ -411,6 +413,11 @@ class Solver:
     def is_fused(self) -> bool:
         """True when a solve is one launch that needs no look from the host (``rmpc_is_fused``)."""
         return bool(self._L.rmpc_is_fused(self._h))
+
+    def is_async(self) -> bool:
+        """True when a device solve only enqueues work and returns (``rmpc_is_async``): fused handles, and the pass
+        kernels under a pass budget."""
+        return bool(self._L.rmpc_is_async(self._h))
 
     def set_profiling(self, enable: bool):
         self._check(self._L.rmpc_set_profiling(self._h, 1 if enable else 0), "rmpc_set_profiling")

@@ -268,6 +268,9 @@ __global__ __launch_bounds__(256) void k_save_duals(const Ws W, const Ws D, int 
 __global__ __launch_bounds__(1024) void k_compact(Ws W, int B, int pass) {
   __shared__ int sums[1024];
   const int tid = threadIdx.x;
+  // (passes enqueued without a host look, rmpc_set_pass_budget: once nothing iterates any more the remaining passes
+  //  are empty launches -- this one too; active_hist was zeroed before the solve)
+  if (pass > 0 && *W.n_act == 0) return;
   const int per = (B + 1023) / 1024;
   const int lo = tid * per, hi = (lo + per < B) ? lo + per : B;
   int cnt = 0;
@@ -1547,6 +1550,9 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
   // stores, and the cost-to-go products of a lane's q entry are formed by the lane itself instead of going
   // through another LDS exchange: three waits per stage instead of about twenty.
   constexpr bool FAST = SLOTS && !DD;
+  // the arms' cost-to-go update on the matrix cores (v_mfma_f64_16x16x4_f64): one wavefront per instance, a state of
+  // 9 .. 15 entries (one tile with the gradient column), at most 8 inputs (two k-steps)
+  constexpr bool MFMA_P = !DD && !SLOTS && LPI == 64 && NX > 8 && NX < 16 && NW <= 8;
   if constexpr (FAST) {
     constexpr int OFF_KFF = NW * NX, OFF_PT = NW * NX + NW, OFF_P = OFF_PT + NP2, OFF_RC = OFF_P + NX;
     // loop-invariant per-lane constants of the Q entries (sum_{a,b} l_a c_b P_ab, see the generic path)
@@ -2105,6 +2111,54 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     }
     WSYNC();
     // -- cost-to-go: P = sym(Qxx + Qxw K), p = qx + Qxw kff ---------------------------------------------
+    if constexpr (MFMA_P) {
+      // The arms, one wavefront per instance: the 14 x 7 x 15 product on the matrix cores.  M = Qxw [K | kff] is one
+      // 16 x 16 tile of v_mfma_f64_16x16x4_f64 (two k-steps of four), accumulated onto C = [Qxx | qx]; its transpose
+      // M^T = [K | kff]^T Qxw^T comes from the same two operand registers swapped, accumulated onto Qxx^T, so that
+      // a lane holds M(i, j) and M(j, i) for its four entries: 14 LDS reads and 4 matrix instructions per lane
+      // instead of 120 reads and 56 multiply-adds (the sums keep the order l = 0 .. NW-1 on top of the Qxx entry).
+      // Operand maps (guide, "Fragment layout"): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+      // C / D[row = (lane >> 4) + 4 r][col = lane & 15], r = 0 .. 3.
+      typedef double v4d __attribute__((ext_vector_type(4)));
+      const int c16 = lane & 15, kq = lane >> 4;
+      const bool cin = c16 < NX;
+      const int cc = cin ? c16 : 0;
+      double a0 = sQ[cc * NV + NX + kq];                                   // Qxw(c16, kq)
+      double a1 = sQ[cc * NV + NX + (4 + kq < NW ? 4 + kq : 0)];           // Qxw(c16, 4 + kq)
+      double b0 = c16 == NX ? skf[kq] : sK[kq * NX + cc];                  // K(kq, c16) | kff(kq)
+      double b1 = c16 == NX ? skf[4 + kq < NW ? 4 + kq : 0] : sK[(4 + kq < NW ? 4 + kq : 0) * NX + cc];
+      a0 = cin ? a0 : 0.0;
+      a1 = (cin && 4 + kq < NW) ? a1 : 0.0;
+      b0 = c16 <= NX ? b0 : 0.0;
+      b1 = (c16 <= NX && 4 + kq < NW) ? b1 : 0.0;
+      v4d cacc, tacc;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = kq + 4 * r;
+        const bool rin = row < NX;
+        const int rr = rin ? row : 0;
+        const double qe = sQ[rr * NV + cc], qt = sQ[cc * NV + rr], qv = sq[rr];
+        cacc[r] = !rin ? 0.0 : (cin ? qe : (c16 == NX ? qv : 0.0));
+        tacc[r] = (rin && cin) ? qt : 0.0;
+      }
+      cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, cacc, 0, 0, 0);
+      tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, tacc, 0, 0, 0);
+      cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, cacc, 0, 0, 0);
+      tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, tacc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = kq + 4 * r;
+        if (row < NX) {
+          if (cin) {
+            const double pn = 0.5 * (cacc[r] + tacc[r]);
+            sP[row * NX + c16] = pn;
+            if (row <= c16) sPt[tri(row, c16)] = pn;
+          } else if (c16 == NX) {
+            sp[row] = cacc[r];
+          }
+        }
+      }
+    } else {
     // entries e < NX*NX are P(i, j); the next NX entries are p(i), written as the same expression with the
     // "column" kff and no transposed partner (a == c, 0.5 (a + a) = a exactly): one instruction stream
     constexpr int PPL2 = (NX * NX + NX + LPI - 1) / LPI;
@@ -2140,6 +2194,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       } else if (e < NX * NX + NX) {
         sp[e - NX * NX] = pn[u];
       }
+    }
     }
     // (the fill of the next stage touches sQ / sq / src only; its barrier orders the sP writes)
   }
@@ -3307,6 +3362,7 @@ struct rmpc_handle {
   int *d_exit = nullptr, *d_iters = nullptr;
   int *h_active = nullptr;  // pinned
   int last_passes = 0;
+  int last_cap = 0;             // passes enqueued by the last solve of the pass kernels
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> ev;   // pool, reused across solves
@@ -3969,6 +4025,12 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
   Phase ph{h->W, B};
   bool migrated = false;
   const bool may_migrate = h->Bpc > 0 && B >= kMigrateMin && !h->env_no_migrate;
+  // A solve with a deadline in passes (rmpc_set_pass_budget) is enqueued whole, without a host look: every kernel
+  // leaves at once when the list of iterating instances is empty, so the call returns immediately and the solve is
+  // ordered with the caller's stream like a fused launch (rmpc_is_async).  Without a deadline the host reads one
+  // counter every few passes (it cannot know how many passes to enqueue) and moves the survivors to the compact
+  // workspace.
+  const bool async = h->pass_budget > 0 && max_passes_override <= 0;
   for (; pass < cap; pass++) {
     const int first = pass == 0;
     { ProfScope ps(h, st, K_SWEEP); if (launch_variant(h, ph, first, pass, st, K_SWEEP)) return -1; }
@@ -3976,7 +4038,7 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, ph.W, ph.B, pass);
     { ProfScope ps(h, st, K_STEP); if (launch_variant(h, ph, first, pass, st, K_STEP)) return -1; }
     if (h->profiling) HIPCHK(hipGetLastError());   // per pass when profiling is on (otherwise once after the loop)
-    if (pass + 1 == next_check && max_passes_override <= 0) {
+    if (!async && pass + 1 == next_check && max_passes_override <= 0) {
       HIPCHK(hipMemcpyAsync(h->h_active, h->W.active_hist + pass, sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
       const int n = *h->h_active;
@@ -3991,7 +4053,8 @@ static int solve_device(rmpc_handle *h, int B, const double *d_xinit, const doub
       next_check += (may_migrate && !migrated) ? 2 : 4;  // look more often while the migration is still ahead
     }
   }
-  h->last_passes = pass;
+  h->last_passes = async ? -2 : pass;   // (-2: on the device, rmpc_last_passes counts the non-empty passes of active_hist)
+  h->last_cap = pass;
   {
     ProfScope ps(h, st, K_UNPACK);
     dim3 g((B + 63) / 64, (M.N * M.nv + 63) / 64);
@@ -4328,6 +4391,7 @@ int rmpc_set_pass_budget(rmpc_handle *h, int passes) {
 }
 
 int rmpc_is_fused(const rmpc_handle *h) { return (h && h->fused) ? 1 : 0; }
+int rmpc_is_async(const rmpc_handle *h) { return (h && (h->fused || h->pass_budget > 0)) ? 1 : 0; }
 
 int rmpc_set_profiling(rmpc_handle *h, int enable) {
   if (!h) return fail("null handle");
@@ -4361,6 +4425,16 @@ int rmpc_last_passes(rmpc_handle *h) {
       return -1;
     h->last_passes = *h->h_passes;
   }
+  if (!h->fused && h->last_passes == -2) {
+    // a solve enqueued without a host look: passes after which instances were still iterating, plus the one that
+    // found them all stopped
+    if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+    h->h_hist.resize(h->last_cap + 1);
+    if (hipMemcpy(h->h_hist.data(), h->W.active_hist, sizeof(int) * h->last_cap, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int p = 0;
+    while (p < h->last_cap && h->h_hist[p] > 0) p++;
+    h->last_passes = p < h->last_cap ? p + 1 : h->last_cap;
+  }
   return h->last_passes;
 }
 
@@ -4374,22 +4448,42 @@ int rmpc_debug_fused_stamps(rmpc_handle *h, long long *out, int nblocks) {
   return 0;
 }
 
-/* test aid: fills the LDS of every CU with NaN patterns (a kernel that owns all 160 KB of a CU's LDS, four
- * blocks per CU worth of launches), so that a test can show that no kernel depends on what it finds there */
-__global__ __launch_bounds__(64) void k_poison_lds(double *sink) {
+/* test aid: NaN patterns into everything a solve could read without having written it -- the LDS of every CU (blocks
+ * that own all 160 KB of a CU, then 64 KB blocks, so that whatever offset a solver kernel's allocation starts at has
+ * been covered), the scratch (private) memory the wavefronts spill to, and the handle's whole device workspace (all
+ * bytes 0xff: NaN as a double, -1 as an int; stored multipliers and the parameters of rmpc_pack_scene_workspace are
+ * thereby forgotten).  A test then shows that no result depends on what a kernel finds in any of them. */
+__global__ __launch_bounds__(64) void k_poison_lds(double *sink, int nbytes) {
   extern __shared__ double pl[];
-  const int n = 64 * 1024 / 8;
+  const int n = nbytes / 8;
   for (int i = threadIdx.x; i < n; i += 64) pl[i] = __longlong_as_double(0x7ff8dead0000beefLL);
   __syncthreads();
   if (sink && threadIdx.x == 0 && blockIdx.x == 0) sink[0] = pl[n - 1];
 }
+__global__ __launch_bounds__(64) void k_poison_scratch(double *sink, int salt) {
+  // 4 KB of private memory per lane, indexed at run time (so that it lives in scratch), filled with NaN patterns
+  // (launched with 40 KB of LDS per block: four wavefronts per CU, like the solver kernels that spill)
+  volatile double buf[512];
+  for (int i = 0; i < 512; i++) buf[i] = __longlong_as_double(0x7ff8dead0000beefLL + i);
+  if (sink && salt == 12345) sink[threadIdx.x] = buf[(salt + threadIdx.x) % 512];
+}
 int rmpc_debug_poison_lds(rmpc_handle *h) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipFuncSetAttribute((const void *)k_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  for (int rep = 0; rep < 4; rep++) hipLaunchKernelGGL(k_poison_lds, dim3(4096), dim3(64), 64 * 1024, h->stream, (double *)nullptr);
-  HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
+  const int sizes[2] = {160 * 1024, 64 * 1024};
+  for (int si = 0; si < 2; si++) {
+    HIPCHK(hipFuncSetAttribute((const void *)k_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize, sizes[si]));
+    for (int rep = 0; rep < 4; rep++)
+      hipLaunchKernelGGL(k_poison_lds, dim3(4096), dim3(64), sizes[si], h->stream, (double *)nullptr, sizes[si]);
+    HIPCHK(hipGetLastError());
+  }
+  for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(k_poison_scratch, dim3(8192), dim3(64), 40 * 1024, h->stream, (double *)nullptr, rep);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(h->ws_base, 0xff, h->ws_bytes, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->have_duals = false;
+  h->packed_B = 0;
   return 0;
 }
 

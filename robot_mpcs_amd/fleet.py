@@ -169,6 +169,7 @@ class MixedFleetShard:
         fused = [f for f in self.fleets if f["s"].is_fused()]
         for f in sorted(fused, key=lambda f: -self._cost(f)):
             self._solve(f)
+        # (under a pass budget the arm's passes are enqueued whole as well, rmpc_is_async: nothing below blocks)
         for f in self.fleets:
             if not f["s"].is_fused():
                 self._solve(f)

@@ -63,12 +63,20 @@ def test_solve_matches_oracle(rt, name, B, seed):
     np.testing.assert_allclose(gpu["obj"], cpu["obj"], rtol=1e-9, atol=1e-9)
 
 
-@pytest.mark.parametrize("name,B", [("cfg1", 3), ("cfg2", 2048), ("cfg3", 512)])
-def test_solve_does_not_depend_on_stale_lds(rt, name, B):
-    """The fused kernel keeps its stage records in LDS; every entry the recursion reads must have been written by the
-    sweep of the same pass.  (Round 2: the defect entries of the last stage were not -- 0 * NaN reached the gains on a
-    box whose previous kernel had left NaN patterns there.)  The LDS of every CU is filled with NaNs before the solve."""
-    sc = rt["make_scenario"](name, B=B, seed=21)
+@pytest.mark.parametrize("name,B,kw", [
+    ("cfg1", 3, {}), ("cfg2", 2048, {}), ("cfg3", 512, {}),
+    # the pass kernels: the arm (its sweep keeps the q blocks, the next stage's state and the costates in LDS columns,
+    # its recursion the stage matrices; 420 B of scratch per lane), a weighted arm, and horizons beyond the fused
+    # kernel's 32 stages (point robot and boxer through k_sweep / k_riccati / k_step, with survivor migration)
+    ("cfg4", 256, {}), ("wc_panda", 64, {}), ("cfg2", 1536, {"time_horizon": 40}), ("cfg3", 192, {"time_horizon": 36}),
+])
+def test_solve_does_not_depend_on_stale_lds(rt, name, B, kw):
+    """Every word a kernel reads from LDS, scratch or the handle's workspace must have been written by the same solve:
+    the stage records of the fused kernel (round 2: the defect entries of the last stage were not -- 0 * NaN reached
+    the gains on a box whose previous kernel had left NaN patterns there), the LDS columns and spill slots of the
+    arm's sweep, the iterate buffers a first pass reads and discards.  Before the second solve the LDS of every CU,
+    the scratch memory and the whole workspace are filled with NaN patterns (``rmpc_debug_poison_lds``)."""
+    sc = rt["make_scenario"](name, B=B, seed=21, **kw)
     s = rt["Solver"](sc.desc, max_batch=B)
     clean = s.solve(sc.xinit, sc.x0, sc.params)
     s.poison_lds()
@@ -526,4 +534,48 @@ def test_is_fused_tells_which_solves_need_no_host_look(rt, monkeypatch):
     sc = rt["make_scenario"]("cfg2", B=4, seed=1)
     s = rt["Solver"](sc.desc, max_batch=4)
     assert not s.is_fused()
+    s.close()
+
+
+def test_budgeted_pass_kernel_solve_needs_no_host_look(rt):
+    """rmpc_is_async: under a pass budget the arm's solve is enqueued whole (no host look) and returns before the
+    device has finished; its results are those of the host-driven loop under the same budget (bit for bit), the
+    non-empty passes are counted on the device, and the call is ordered with the caller's stream."""
+    import torch
+    B = 192
+    sc = rt["make_scenario"]("cfg4", B=B, seed=11)
+    s = rt["Solver"](sc.desc, max_batch=B)
+    assert not s.is_fused() and not s.is_async()
+    full = s.solve(sc.xinit, sc.x0, sc.params)
+    need = s.last_passes()
+    exact = None
+    for budget in (need + 6, 9):
+        s.set_pass_budget(budget)
+        assert s.is_async()
+        r = s.solve(sc.xinit, sc.x0, sc.params)
+        if exact is None:
+            exact = s.last_passes()   # (the host loop looks every few passes: its count is rounded up)
+            assert need - 4 <= exact <= need and exact > 9
+        else:
+            assert s.last_passes() == budget
+        if budget > need:
+            for key in ("z", "exitflag", "iters", "obj", "kkt"):
+                assert np.array_equal(r[key], full[key]), key
+        else:
+            cut = r["exitflag"] == 0
+            assert cut.any() and np.array_equal(r["z"][~cut], full["z"][~cut])
+    # stream order: outputs consumed by a later kernel on the same stream, no synchronisation in between
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xi, x0, pa = t(sc.xinit), t(sc.x0), t(sc.params)
+    z = torch.zeros((B, s.N, s.nvar), dtype=torch.float64, device=dev)
+    ef = torch.full((B,), -99, dtype=torch.int32, device=dev); it = torch.zeros(B, dtype=torch.int32, device=dev)
+    kk = torch.zeros(B, dtype=torch.float64, device=dev); ob = torch.zeros(B, dtype=torch.float64, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        s.solve_device(B, xi, x0, pa, z, ef, it, kk, ob, stream=st.cuda_stream)
+        zc = z.clone()
+    torch.cuda.synchronize()
+    assert np.array_equal(zc.cpu().numpy(), r["z"])
     s.close()
