@@ -74,7 +74,9 @@ def parse():
                     "Not an iteration cap below --max-iter: 20 iterations fit in 21 passes; what it cuts are line searches that backtrack")
     ap.add_argument("--pass-budget-boxer", type=int, default=40, help="cfg5: the boxers' deadline if it differs (0 = --pass-budget)")
     ap.add_argument("--acc-iters", type=int, default=3, help="cfg5: acceptable-termination window of the real-time loop (consecutive stagnant feasible iterations; the configs' default is 8)")
-    ap.add_argument("--episode", type=int, default=40, help="cfg5 only: control steps per episode (then every instance restarts)")
+    ap.add_argument("--max-dwell", type=int, default=150, help="cfg5: control steps after which an instance takes its next goal even if it has not arrived")
+    ap.add_argument("--mu-regoal-boxer", type=float, default=-1.0, help="cfg5 (development): barrier parameter a boxer's first solve after a goal hand-over restarts from (default: the fleet's)")
+    ap.add_argument("--cfg5-steps", type=int, default=400, help="control steps of the cfg5 loop carried in the default line (extra.cfg5)")
     return ap.parse_args()
 
 
@@ -297,36 +299,32 @@ def cpu_baseline(leg, gpu_z, gpu_exit, Solver, make_scenario, local_rank):
 
 def run_cfg5(args, fleet, dev, rank, world, dd, fence, steps, warmup):
     """BASELINE configs[4] on this rank's shard: the device-resident closed loop (scene packing + solve + plant step +
-    shifted plan + warm multipliers), timed like the headline (barrier + synchronize on both sides, max over ranks);
-    returns value / ms_per_step / config / loop / per_fleet on rank 0."""
+    shifted plan + warm multipliers + goal hand-over), timed like the headline (barrier + synchronize on both sides,
+    max over ranks).  A STEADY loop: no episodes, no resets of the fleet -- an instance takes a new goal when it
+    arrives, an instance whose solve failed goes back to its start state (rmpc_retarget_device); the statistics of
+    every control step are summed on the device.  Returns value / ms_per_step / config / loop / per_fleet on rank 0."""
     import numpy as np
     part = fleet.partition_mixed(8192 * world, world)[rank]
     counts = {k: hi - lo for k, (lo, hi) in part.items()}
     shard = fleet.MixedFleetShard(counts, dev, seed=7 + rank, previous_plan=True, warm_duals=True,
                                   options={"max_iter": args.max_iter, "acc_iters": args.acc_iters},
                                   pass_budget={"cfg2": args.pass_budget, "cfg3": args.pass_budget_boxer or args.pass_budget,
-                                               "cfg4": args.pass_budget})
+                                               "cfg4": args.pass_budget}, steady=True, max_dwell=args.max_dwell,
+                                  mu_regoal=({"cfg3": args.mu_regoal_boxer} if args.mu_regoal_boxer >= 0 else None))
     for _ in range(warmup):
         shard.tick()
+    shard.steady_stats(reset=True)
     fence()
     times = []
     t0 = time.perf_counter()
     for i in range(steps):
         t1 = time.perf_counter()
-        if i % args.episode == 0:
-            shard.reset()          # new episode: start states, cold plan, cold multipliers
         shard.tick()
         times.append(1e3 * (time.perf_counter() - t1))
     fence()
     elapsed = fleet.max_over_ranks(time.perf_counter() - t0, dd, dev)
-    # exit-flag statistics: one further episode outside the timed region (reading them costs a host sync per step)
-    acc = {k: np.zeros(5) for k in counts}
-    shard.reset()
-    for _ in range(args.episode):
-        shard.tick()
-        for k, v in shard.stats().items():
-            acc[k] += np.array(v, dtype=float) / args.episode
-    st = np.array([acc[k] for k in ("cfg2", "cfg3", "cfg4")]).ravel()
+    ss = shard.steady_stats(reset=True)
+    st = np.array([np.concatenate([ss[k]["acc"], ss[k]["events"]]) for k in ("cfg2", "cfg3", "cfg4")]).ravel()
     allst = fleet.gather_stats(st, dd, dev)
     shard.close()
     if rank != 0:
@@ -335,21 +333,22 @@ def run_cfg5(args, fleet, dev, rank, world, dd, fence, steps, warmup):
     total = 8192 * world
     per = {}
     for i, k in enumerate(("cfg2", "cfg3", "cfg4")):
-        a = allst[:, 5 * i: 5 * i + 5]
-        B = counts[k]
-        per[k] = {"instances_per_gpu": B, "usable_share": float((a[:, 0] + a[:, 1]).sum() / (B * world)),
-                  "iteration_cap_per_step": float(a[:, 2].sum()), "failed_per_step": float(a[:, 3].sum()),
-                  "iters_mean": float(a[:, 4].mean())}
+        a = allst[:, 8 * i: 8 * i + 8].sum(axis=0)
+        n = counts[k] * world * steps
+        per[k] = {"instances_per_gpu": counts[k], "usable_share": float((a[0] + a[1]) / n),
+                  "cut_by_deadline_or_iteration_cap_per_step": float(a[2] / steps), "failed_per_step": float(a[3] / steps),
+                  "iters_mean": float(a[4] / n), "arrivals_per_step": float(a[5] / steps),
+                  "dwell_timeouts_per_step": float(a[6] / steps), "resets_per_step": float(a[7] / steps)}
     return dict(value=total * steps / elapsed, ms_per_step=1e3 * elapsed / steps, steps=steps,
                 config={"workload": WORKLOADS["cfg5"], "instances_per_gpu": 8192, "max_iter": args.max_iter,
                         "acc_iters": args.acc_iters, "pass_budget": args.pass_budget,
                         "pass_budget_boxer": args.pass_budget_boxer or args.pass_budget,
-                        "episode_steps": args.episode,
+                        "loop": "steady: new goal on arrival (or after %d control steps), start state after a failed solve; no episodes" % args.max_dwell,
                         "warm_start": "shifted plan + multipliers (rmpc_set_warm_start)",
                         "parallelism": f"{world} x per-robot-type blocks (fleet.partition_mixed), no data-path collective"},
                 loop={"rate_hz": float(steps / elapsed), "ms_p50": float(np.percentile(times, 50)),
-                      "ms_p90": float(np.percentile(times, 90)), "ms_max": float(times.max()),
-                      "deadline_10ms_hit_rate_rank0": float((times <= 10.0).mean())},
+                      "ms_p90": float(np.percentile(times, 90)), "ms_p99": float(np.percentile(times, 99)), "ms_max": float(times.max()),
+                      "deadline_10ms_hit_rate_rank0": float((times <= 10.0).mean()), "consecutive_steps": int(steps)},
                 per_fleet=per)
 
 
@@ -482,11 +481,11 @@ def main():
                            "roofline": kernel_report(pr, wall, 4, lo.B, d2, st["iters_mean"]) if pr else None}
             lo.close()
 
-    # BASELINE configs[4] (mixed fleet, 100 Hz loop) in the same line: two episodes of the closed loop
+    # BASELINE configs[4] (mixed fleet, 100 Hz loop) in the same line: 400 consecutive control steps of the steady loop
     # (`--config cfg5` runs it alone under the bench contract)
     cfg5_extra = None
     if not args.no_legs and cfg == "cfg2" and world == 1:
-        cfg5_extra = run_cfg5(args, fleet, dev, rank, world, dd, fence, 2 * args.episode, 3)
+        cfg5_extra = run_cfg5(args, fleet, dev, rank, world, dd, fence, args.cfg5_steps, 10)
 
     if rank == 0:
         d = dict(leg.d, _cfg=cfg)

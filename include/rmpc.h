@@ -237,6 +237,22 @@ int rmpc_advance_device(rmpc_handle *h, int B, const double *d_z_prev, double *d
 int rmpc_advance_device_flags(rmpc_handle *h, int B, const double *d_z_prev, const int32_t *d_exitflag, double *d_xinit,
                               double *d_x0, int previous_plan, void *stream);
 
+/* Steady closed loop (fleet harness; the examples of the reference hand the planner its next goal whenever the driver
+ * has one -- setGoalReaching every control step with the next waypoint, examples/boxer_example_global.py:203-212).
+ * Called after rmpc_advance_device_flags: an instance whose end link has arrived within `tol` of its goal, or has
+ * spent `max_dwell` control steps on it (0: no limit), takes the next goal of its pool d_goal_pool [B][pool_len][3]
+ * (cursor d_cursor [B], dwell counter d_dwell [B], both int32 on the device, zero-initialised by the caller); an
+ * instance whose solve FAILED (exitflag < 0) is put back to its start state d_x_start [B][nx] with a cold plan and takes
+ * its next goal as well.  mu_regoal > 0 (with rmpc_set_warm_start(1)): the next solve of an instance that has just taken
+ * a new goal keeps its multipliers but restarts its barrier parameter from mu_regoal (a new goal moves the optimum;
+ * 1000 x the converged barrier parameter is too small a neighbourhood for it); 0: plain warm start.
+ * d_goal [B][3] is the array the scene (rmpc_scene.goal) points at.  d_counts (may be NULL):
+ * eight int32 counters, incremented: arrivals, dwell time-outs, resets, then the control step's exit flags (1, 2, 0,
+ * < 0) and the sum of d_iters (may be NULL) -- loop statistics without a host read per control step. */
+int rmpc_retarget_device(rmpc_handle *h, int B, double *d_xinit, double *d_x0, const int32_t *d_exitflag, double *d_goal,
+                         const double *d_goal_pool, int pool_len, int32_t *d_cursor, int32_t *d_dwell, const double *d_x_start,
+                         double tol, int max_dwell, double mu_regoal, int32_t *d_counts, const int32_t *d_iters, void *stream);
+
 /* Free-space decomposition on the device: for each of the B*N seed points
  * (e.g. the planned lidar position of instance b at stage k) at most K half-planes
  * [a(3), d] from instance b's point cloud of P <= 64 points, greedy nearest-point rule and dummy

@@ -60,13 +60,23 @@ def cont_dyn(desc, x, u):
     return np.array([np.cos(th) * v, np.sin(th) * v, w, 0.0, 0.0, 0.0, u[0], u[1]])
 
 
+# ERK2 tableau of the discretisation.  FORCES Pro's choice is not verifiable here: the product and
+# the C oracle use the explicit midpoint rule; "heun" (explicit trapezoid) exists only for the sensitivity line of
+# tests/golden/make_scipy_golden.py (how far the first control moves if the other ERK2 tableau is the true one).
+ERK2_TABLEAU = "midpoint"
+
+
 def dynamics(desc, x, u, nodes=5):
     h = desc["dt"] / nodes
     x = np.array(x, dtype=float)
     for _ in range(nodes):
         k1 = cont_dyn(desc, x, u)
-        k2 = cont_dyn(desc, x + 0.5 * h * k1, u)
-        x = x + h * k2
+        if ERK2_TABLEAU == "heun":
+            k2 = cont_dyn(desc, x + h * k1, u)
+            x = x + 0.5 * h * (k1 + k2)
+        else:
+            k2 = cont_dyn(desc, x + 0.5 * h * k1, u)
+            x = x + h * k2
     return x
 
 
@@ -308,5 +318,21 @@ class StructuredNLP(HorizonNLP):
                          {"type": "ineq", "fun": lambda y: self.ineq(D * y), "jac": lambda y: self.ineq_jac(D * y) * D[None, :]}],
             options={"maxiter": maxiter, "ftol": ftol},
         )
+        res.x = D * res.x
+        return self.unpack(res.x), res
+
+    def solve_trust_constr(self, Z0, maxiter=3000, gtol=1e-9, xtol=1e-12):
+        """The same NLP through scipy's trust-region interior-point method (``trust-constr``, BFGS model of the
+        Lagrangian): a second algorithm family beside SLSQP's active-set SQP."""
+        from scipy.optimize import BFGS, Bounds, NonlinearConstraint, minimize
+        D = self.var_scale()
+        y0 = self.pack(np.asarray(Z0, dtype=float).reshape(self.N, self.nv)) / D
+        lo = np.array([-np.inf if a is None else a / dd for (a, b), dd in zip(self.bounds(), D)])
+        hi = np.array([np.inf if b is None else b / dd for (a, b), dd in zip(self.bounds(), D)])
+        cons = [NonlinearConstraint(lambda y: self.eq(D * y), 0.0, 0.0, jac=lambda y: self.eq_jac(D * y) * D[None, :], hess=BFGS()),
+                NonlinearConstraint(lambda y: self.ineq(D * y), 0.0, np.inf, jac=lambda y: self.ineq_jac(D * y) * D[None, :], hess=BFGS())]
+        res = minimize(lambda y: self.objective(D * y), y0, jac=lambda y: D * self.grad(D * y), hess=BFGS(), method="trust-constr",
+                       bounds=Bounds(lo, hi, keep_feasible=False), constraints=cons,
+                       options={"maxiter": maxiter, "gtol": gtol, "xtol": xtol, "initial_barrier_parameter": 0.1})
         res.x = D * res.x
         return self.unpack(res.x), res

@@ -72,7 +72,7 @@ EXPORTED_SYMBOLS = [
     "rmpc_version", "rmpc_source_hash", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
     "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_warm_start", "rmpc_set_pass_budget", "rmpc_is_fused", "rmpc_is_async", "rmpc_set_profiling", "rmpc_get_profile",
     "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep", "rmpc_spec_source", "rmpc_spec_name", "rmpc_spec_for", "rmpc_debug_poison_lds",
-    "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_pack_scene_workspace", "rmpc_solve_batch_packed_device", "rmpc_advance_device", "rmpc_advance_device_flags", "rmpc_free_space_device",
+    "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_pack_scene_workspace", "rmpc_solve_batch_packed_device", "rmpc_advance_device", "rmpc_advance_device_flags", "rmpc_retarget_device", "rmpc_free_space_device",
 ]
 
 _lib = None
@@ -188,6 +188,8 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_advance_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.rmpc_advance_device_flags.restype = C.c_int
     L.rmpc_advance_device_flags.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.rmpc_retarget_device.restype = C.c_int
+    L.rmpc_retarget_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_double, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rmpc_free_space_device.restype = C.c_int
     L.rmpc_free_space_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     if L.rmpc_desc_size() != C.sizeof(RmpcDesc):
@@ -399,6 +401,16 @@ class Solver:
                                                C.c_void_p(xinit.data_ptr()), C.c_void_p(x0.data_ptr()),
                                                1 if previous_plan else 0, st)
         self._check(rc, "rmpc_advance_device_flags")
+
+    def retarget_device(self, B, xinit, x0, exitflag, goal, goal_pool, cursor, dwell, x_start, tol, max_dwell=0, counts=None,
+                        iters=None, mu_regoal=0.0, stream=None):
+        """Steady closed loop (``rmpc_retarget_device``): next goal from the instance's pool on arrival / dwell time-out,
+        reset to the start state (and next goal) after a failed solve.  All arguments are device tensors."""
+        st = _stream_arg(stream)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        rc = self._L.rmpc_retarget_device(self._h, int(B), p(xinit), p(x0), p(exitflag), p(goal), p(goal_pool), int(goal_pool.shape[1]),
+                                          p(cursor), p(dwell), p(x_start), float(tol), int(max_dwell), float(mu_regoal), p(counts), p(iters), st)
+        self._check(rc, "rmpc_retarget_device")
 
     def set_warm_start(self, enable: bool):
         """Closed loops: start every solve from the multipliers of the previous solve of the same batch

@@ -3257,6 +3257,67 @@ __global__ __launch_bounds__(256) void k_advance(const DevModel M, const double 
   (void)NS;
 }
 
+// Steady closed loop (the examples hand the planner a new goal whenever the driver has one,
+// setGoalReaching every control step in examples/boxer_example_global.py:203-212): one lane per instance looks at the
+// state the plant step has just produced and gives the instance its next goal from its pool when the end link has
+// arrived (within tol of the goal) or has dwelt max_dwell control steps on this goal; an instance whose solve FAILED
+// (exitflag < 0: infeasible or diverged, a state no plan leads out of) is put back to its start state with a cold
+// plan and takes its next goal too.  The goals live in the scene's goal array, so the next parameter packing sees them.
+template <class C>
+__global__ __launch_bounds__(256) void k_retarget(const DevModel M, const DevTables *__restrict__ Tp, int B, double *__restrict__ xinit,
+                                                  double *__restrict__ x0, const int *__restrict__ exitflag, double *__restrict__ goal,
+                                                  const double *__restrict__ pool, int P, int *__restrict__ cursor, int *__restrict__ dwell,
+                                                  const double *__restrict__ x_start, double tol, int max_dwell, int *__restrict__ counts,
+                                                  const int *__restrict__ iters, double *__restrict__ wmu, double wmu_regoal) {
+  constexpr int NQ = C::NQ, NX = C::NX, NV = C::NV;
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  const bool in = b < B;
+  // statistics of the control step, summed on the device (no host read inside the loop): exit flags and iterations
+  if (counts && exitflag) {
+    const int ef = in ? exitflag[b] : -1000;
+    const int it = (in && iters) ? iters[b] : 0;
+    const int cls[4] = {ef == 1, ef == 2, ef == 0, ef < 0 && ef > -1000};
+    for (int c = 0; c < 4; c++) {
+      const unsigned long long mk = __ballot(cls[c]);
+      if ((threadIdx.x & 63) == 0 && mk) atomicAdd(&counts[3 + c], __popcll(mk));
+    }
+    int si = it;
+    for (int off = 32; off >= 1; off >>= 1) si += __shfl_xor(si, off, 64);
+    if ((threadIdx.x & 63) == 0 && si) atomicAdd(&counts[7], si);
+  }
+  if (!in) return;
+  const RtView v(M, *Tp);
+  const bool failed = exitflag && exitflag[b] < 0;
+  if (failed) {
+    for (int j = 0; j < NX; j++) xinit[(size_t)b * NX + j] = x_start[(size_t)b * NX + j];
+    for (int k = 0; k < M.N; k++)
+      for (int j = 0; j < NV; j++) x0[((size_t)b * M.N + k) * NV + j] = j < NX ? x_start[(size_t)b * NX + j] : 0.0;
+  }
+  double q[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; j++) q[j] = xinit[(size_t)b * NX + j];
+  Kin<C> kin;
+  kin.compute(v, q);
+  Vec3 J[NQ];
+  const Vec3 pt = kin.template point<0>(v, J);   // slot 0: the goal's end frame (build_tables)
+  const double dx = pt.x - goal[(size_t)b * 3], dy = pt.y - goal[(size_t)b * 3 + 1], dz = pt.z - goal[(size_t)b * 3 + 2];
+  const bool arrived = sqrt(dx * dx + dy * dy + dz * dz) < tol;
+  int dw = dwell[b] + 1;
+  const bool late = max_dwell > 0 && dw >= max_dwell;
+  if (arrived || late || failed) {
+    const int c = cursor[b] + 1;
+    cursor[b] = c;
+    const double *g = pool + ((size_t)b * P + (size_t)(c % P)) * 3;
+    goal[(size_t)b * 3] = g[0]; goal[(size_t)b * 3 + 1] = g[1]; goal[(size_t)b * 3 + 2] = g[2];
+    dw = 0;
+    // a new goal moves the optimum: the multipliers of the last solve stay, the barrier parameter of the next solve
+    // restarts from mu_regoal (stored so that warm_mu() yields it) instead of 1000 x the converged one
+    if (wmu && wmu_regoal > 0.0 && !failed) wmu[b] = wmu_regoal;
+    if (counts) atomicAdd(&counts[failed ? 2 : (arrived ? 0 : 1)], 1);
+  }
+  dwell[b] = dw;
+}
+
 // ===========================================================================
 // Free-space decomposition: lidar point cloud -> at most K half-planes
 // around a seed point, one lane per (instance, stage) seed.  Greedy rule of the reference
@@ -4364,6 +4425,31 @@ int rmpc_advance_device_flags(rmpc_handle *h, int B, const double *d_z_prev, con
 int rmpc_advance_device(rmpc_handle *h, int B, const double *d_z_prev, double *d_xinit, double *d_x0,
                         int previous_plan, void *stream) {
   return rmpc_advance_device_flags(h, B, d_z_prev, nullptr, d_xinit, d_x0, previous_plan, stream);
+}
+
+int rmpc_retarget_device(rmpc_handle *h, int B, double *d_xinit, double *d_x0, const int32_t *d_exitflag, double *d_goal,
+                         const double *d_goal_pool, int pool_len, int32_t *d_cursor, int32_t *d_dwell, const double *d_x_start,
+                         double tol, int max_dwell, double mu_regoal, int32_t *d_counts, const int32_t *d_iters, void *stream) {
+  if (!h || !d_xinit || !d_x0 || !d_goal || !d_goal_pool || !d_cursor || !d_dwell || !d_x_start) return fail("null argument");
+  if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
+  if (pool_len < 1) return fail("goal pool must hold at least one goal per instance");
+  if (!h->desc.has_goal) return fail("the model has no GoalReaching objective");
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g((B + 255) / 256), t(256);
+  const int *ef = (const int *)d_exitflag;
+  double *const wmu = h->warm_mode ? (h->fused ? h->F.wmu : h->W.wmu) : nullptr;
+  const double wmu_regoal = mu_regoal > 0.0 ? mu_regoal / kWarmKappa : 0.0;
+#define RMPC_RT(ID, R, NQ, NS)                                                                                              \
+  case ID: hipLaunchKernelGGL((k_retarget<Cfg<R, NQ, NS>>), g, t, 0, st, h->M, h->d_T, B, d_xinit, d_x0, ef, d_goal, d_goal_pool, \
+                              pool_len, (int *)d_cursor, (int *)d_dwell, d_x_start, tol, max_dwell, (int *)d_counts, (const int *)d_iters, wmu, wmu_regoal); break;
+  switch (h->variant) {
+    RMPC_RT(0, RMPC_ROBOT_CHAIN, 3, 0) RMPC_RT(1, RMPC_ROBOT_CHAIN, 3, 1) RMPC_RT(2, RMPC_ROBOT_CHAIN, 7, 0)
+    RMPC_RT(3, RMPC_ROBOT_CHAIN, 7, 1) RMPC_RT(4, RMPC_ROBOT_DIFFDRIVE, 3, 0) RMPC_RT(5, RMPC_ROBOT_DIFFDRIVE, 3, 1)
+  }
+#undef RMPC_RT
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 int rmpc_free_space_device(int B, int N, int P, int K, double max_radius, const double *d_points,

@@ -98,14 +98,26 @@ class MixedFleetShard:
     (one number, or one per block name): deadline of every solve in passes (instances still iterating return their
     last accepted iterate, flag 0)."""
 
+    # steady loop: arrival tolerance of the end link [m] and goals per instance
+    ARRIVE_TOL = {"cfg2": 0.25, "cfg3": 0.35, "cfg4": 0.10}
+    POOL = 16
+    # barrier parameter the first solve after a goal hand-over restarts from (rmpc_retarget_device)
+    MU_REGOAL = {"cfg2": 0.0, "cfg3": 1e-1, "cfg4": 0.0}
+
     def __init__(self, counts: dict, device, seed: int = 7, previous_plan: bool = True, warm_duals: bool = True,
-                 options: dict | None = None, pass_budget=0):
+                 options: dict | None = None, pass_budget=0, steady: bool = False, max_dwell: int = 150,
+                 mu_regoal: dict | None = None):
         import torch
         from robot_mpcs_amd._lib import Solver
         from robot_mpcs_amd import scenarios as sn
         self.torch, self.dev = torch, device
         self.previous_plan = bool(previous_plan)
         self.warm_duals = bool(warm_duals and previous_plan)
+        # steady: no episodes -- an instance takes a new goal when it arrives (or after max_dwell control steps), an
+        # instance whose solve failed goes back to its start state (rmpc_retarget_device); the loop runs indefinitely
+        self.steady = bool(steady)
+        self.max_dwell = int(max_dwell)
+        self.mu_regoal = dict(self.MU_REGOAL, **(mu_regoal or {}))
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
         limits = {"cfg2": (sn.POINT_LIMITS, sn.POINT_LIMITS_U), "cfg3": (sn.BOXER_LIMITS, sn.BOXER_LIMITS_U),
                   "cfg4": (sn.PANDA_LIMITS, sn.PANDA_LIMITS_U)}
@@ -133,12 +145,21 @@ class MixedFleetShard:
                 rad = sc.extra.get("obst_radius", np.full(sc.extra["obst_pos"].shape[:2], 0.1))
                 ten["obst"] = t(np.concatenate([sc.extra["obst_pos"], rad[:, :, None]], axis=2))
             N, nv = d["N"], s.nvar
-            self.fleets.append(dict(
+            extra = {}
+            if self.steady:
+                pool = goal_pool(name, sc, self.POOL, seed + 1000)
+                extra = dict(pool=t(pool), cursor=torch.zeros(B, dtype=torch.int32, device=device),
+                             dwell=torch.zeros(B, dtype=torch.int32, device=device),
+                             # [arrivals, dwell time-outs, resets, converged, acceptable, cut (iteration cap / deadline),
+                             #  failed, iterations]: summed over the control steps by rmpc_retarget_device
+                             counts=torch.zeros(8, dtype=torch.int32, device=device))
+            self.fleets.append(dict(extra, 
                 name=name, B=B, s=s, sc=sc, scene=s.make_scene(sc.setup["mpc"]["weights"], **ten),
                 x=t(sc.xinit), x0=t(sc.x0), x_start=t(sc.xinit), x0_start=t(sc.x0),
                 z=torch.empty((B, N, nv), dtype=torch.float64, device=device),
                 ef=torch.empty(B, dtype=torch.int32, device=device), it=torch.empty(B, dtype=torch.int32, device=device),
                 kkt=torch.empty(B, dtype=torch.float64, device=device), obj=torch.empty(B, dtype=torch.float64, device=device),
+                goal=ten["goal"],
                 stream=torch.cuda.Stream(device=device)))   # (a higher dispatch priority for the arm's stream: no effect, measured twice)
         torch.cuda.synchronize(device)
 
@@ -154,6 +175,10 @@ class MixedFleetShard:
         f["s"].solve_packed_device(f["B"], f["x"], f["x0"], f["z"], f["ef"], f["it"], f["kkt"], f["obj"], stream=st)
         f["s"].advance_device(f["B"], f["z"], f["x"], f["x0"], previous_plan=self.previous_plan, stream=st,
                               exitflag=f["ef"])
+        if self.steady:
+            f["s"].retarget_device(f["B"], f["x"], f["x0"], f["ef"], f["goal"], f["pool"], f["cursor"], f["dwell"], f["x_start"],
+                                   self.ARRIVE_TOL[f["name"]], self.max_dwell, counts=f["counts"], iters=f["it"],
+                                   mu_regoal=self.mu_regoal[f["name"]], stream=st)
 
     def tick(self, sync: bool = True):
         """One control step of the whole shard.  A fused solve fills every SIMD with one long-lived wavefront, and a
@@ -205,6 +230,58 @@ class MixedFleetShard:
                               float(f["it"].float().mean())]
         return out
 
+    def steady_stats(self, reset: bool = True):
+        """steady loop: per block [converged, acceptable, cut (iteration cap / deadline), failed, iterations] summed over
+        the control steps since the last call, and [arrivals, dwell time-outs, resets]; one host read per block"""
+        out = {}
+        cur = self.torch.cuda.current_stream(self.dev)
+        for f in self.fleets:
+            cur.wait_stream(f["stream"])
+            c = f["counts"].cpu().numpy().astype(np.float64)
+            out[f["name"]] = dict(acc=c[3:8].copy(), events=c[:3].copy())
+            if reset:
+                f["counts"].zero_()
+                f["stream"].wait_stream(cur)
+        return out
+
     def close(self):
         for f in self.fleets:
             f["s"].close()
+
+
+def goal_pool(name: str, sc, P: int, seed: int):
+    """[B, P, 3] goals per instance for the steady loop; goal 0 is the scenario's.  The mobile robots get LOCAL goals, a
+    random walk of 2 .. 4 m steps (boxers 1.5 .. 3 m) inside the arena and clear of the instance's obstacles -- what the
+    reference's driver with a global planner hands the planner (the next waypoint of a path, get_local_goal,
+    examples/boxer_example_global.py:203-212), not a new task at the other end of the map; the arms get goals drawn
+    like the scenario's own."""
+    rng = np.random.default_rng(seed)
+    g0 = np.asarray(sc.extra["goal"], dtype=np.float64)
+    B = g0.shape[0]
+    pool = np.zeros((B, P, 3))
+    pool[:, 0] = g0
+    r_body = float(sc.extra["r_body"])
+    if name == "cfg4":
+        pool[:, 1:] = np.array([0.1, -0.6, 0.4]) + rng.uniform(-0.15, 0.15, size=(B, P - 1, 3))
+        return pool
+    if "obst_dyn" in sc.extra:
+        opos = sc.extra["obst_dyn"].reshape(B, -1, 9)[:, :, :2]
+        clear = np.full(opos.shape[:2], 0.1 + r_body + 1.0)
+        lim, step = 8.5, (1.5, 3.0)
+    else:
+        opos = sc.extra["obst_pos"][:, :, :2]
+        clear = sc.extra["obst_radius"] + r_body + 0.2
+        lim, step = 8.0, (2.0, 4.0)
+    for j in range(1, P):
+        todo = np.ones(B, dtype=bool)
+        while todo.any():
+            idx = np.flatnonzero(todo)
+            k = idx.size
+            ang = rng.uniform(-np.pi, np.pi, size=k)
+            ln = rng.uniform(step[0], step[1], size=k)
+            cand = pool[idx, j - 1, :2] + ln[:, None] * np.stack([np.cos(ang), np.sin(ang)], axis=1)
+            ok = np.all(np.abs(cand) <= lim, axis=1)
+            ok &= np.all(np.linalg.norm(cand[:, None, :] - opos[idx], axis=2) > clear[idx], axis=1)
+            pool[idx[ok], j, :2] = cand[ok]
+            todo[idx[ok]] = False
+    return pool

@@ -161,6 +161,65 @@ def test_mixed_fleet_real_time_settings(rt):
     shard.close()
 
 
+def test_mixed_fleet_steady_loop_full_shard(rt):
+    """BASELINE configs[4] at the real per-GPU shard (4096 point robots + 3072 boxers + 1024 arms) as a STEADY loop, the
+    way `bench.py --config cfg5` runs it (iteration limit 20, acceptable window 3, deadlines 24 / 40 / 24 passes): 400
+    consecutive control steps, nothing is reset -- an instance takes its next goal when it arrives
+    (rmpc_retarget_device), an instance whose solve failed goes back to its start state.  Bars: usable plans (exit
+    flag 1 or 2) for >= 95 % of every robot type over the 400 steps, >= 95 % of the control steps inside the 10 ms
+    of the 100 Hz loop, goals are handed over, and the oracle -- cold-started from the device's own state, shifted plan
+    and current goal of the last step -- reaches the same first control on a sample."""
+    import time
+    import torch
+    from robot_mpcs_amd import fleet
+    counts = {"cfg2": 4096, "cfg3": 3072, "cfg4": 1024}
+    dev = torch.device("cuda:0")
+    shard = fleet.MixedFleetShard(counts, dev, seed=7, previous_plan=True, warm_duals=True,
+                                  options={"max_iter": 20, "acc_iters": 3}, pass_budget={"cfg2": 24, "cfg3": 40, "cfg4": 24},
+                                  steady=True, max_dwell=150)
+    assert shard.instances == 8192
+    for _ in range(10):
+        shard.tick()
+    shard.steady_stats(reset=True)
+    steps = 400
+    ms = []
+    for step in range(steps):
+        if step == steps - 1:   # inputs of the last control step, for the oracle
+            torch.cuda.synchronize()
+            snap = {f["name"]: (f["x"].cpu().numpy().copy(), f["x0"].cpu().numpy().copy(), f["goal"].cpu().numpy().copy())
+                    for f in shard.fleets}
+        t = time.perf_counter()
+        shard.tick()
+        ms.append(1e3 * (time.perf_counter() - t))
+    ss = shard.steady_stats()
+    ms = np.array(ms)
+    assert (ms <= 10.0).mean() >= 0.95, (np.percentile(ms, [50, 90, 99]), ms.max())
+    for name, st in ss.items():
+        conv, acc, cut, failed, iters = st["acc"]
+        n = counts[name] * steps
+        assert conv + acc + cut + failed == n, (name, st)
+        assert (conv + acc) / n >= 0.95, (name, st)
+        assert failed / n <= 0.01, (name, st)
+        assert st["events"][0] > 0, (name, st)          # robots do arrive and get their next goal
+    for f in shard.fleets:
+        o = rt["Oracle"](f["sc"].desc)
+        x, x0, goal = snap[f["name"]]
+        z = f["z"].cpu().numpy(); ef = f["ef"].cpu().numpy()
+        nxs = o.nx + o.ns
+        og = int(f["sc"].desc["off_goal"])
+        tried = same = 0
+        for b in range(0, f["B"], max(1, f["B"] // 12)):
+            params = f["sc"].params[b].reshape(o.N, -1).copy()
+            params[:, og:og + 3] = goal[b]
+            r = o.solve(x[b], x0[b], params)
+            if r["exitflag"] in (1, 2) and ef[b] in (1, 2):
+                tried += 1
+                du = np.abs(r["z"][0, nxs:] - z[b, 0, nxs:]).max()
+                same += du <= 1e-3 * max(1.0, np.abs(r["z"][0, nxs:]).max())
+        assert tried >= 8 and same >= 0.75 * tried, (f["name"], tried, same)
+    shard.close()
+
+
 @pytest.mark.parametrize("name,B", [("cfg2", 333), ("cfg3", 200)])
 def test_launch_order_of_warm_fused_launches_changes_no_result(rt, name, B, monkeypatch):
     """A warm-started fused launch takes the instances in the order of their previous solve's passes, longest first
