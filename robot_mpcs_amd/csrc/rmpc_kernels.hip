@@ -2494,6 +2494,258 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
 }
 
 // ===========================================================================
+// k_riccati_lane: the same decisions and recursion with ONE LANE PER INSTANCE
+// ===========================================================================
+// The "tiny batched" layout of the recursion (round 3, review item 1a): 64 instances per wavefront, the cost-to-go,
+// the dense stage block and the gains of an instance in its lane's registers, no LDS, no exchange between lanes; a
+// stage is a few hundred dependent-free multiply-adds per lane.  A wavefront costs the same ~900 instructions per
+// stage whether 2 or 64 of its lanes hold an instance, so the layout pays once the batch fills wavefronts that would
+// otherwise each carry one instance: it is selected for lists of at least kLaneMin instances (holonomic chains with
+// n <= 3; the arm's blocks do not fit a lane's registers), k_riccati's one-instance-per-wavefront blocks below that.
+// Same arithmetic per entry as riccati_recursion's generic path (closed-form [A|B]^T P [A|B], Cholesky with Newton
+// reciprocal square roots, symmetrised cost-to-go); the stage partials are summed in stage order instead of by a
+// shuffle tree (a rounding-level difference in the merit value).
+constexpr int kLaneMin = 16384;
+template <class C>
+__global__ __launch_bounds__(64) void k_riccati_lane(const DevModel M, const Ws W, const int B, const int first) {
+  constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NV = C::NV, NW = C::NW;
+  static_assert(C::ROBOT == RMPC_ROBOT_CHAIN && NQ <= 3, "lane-per-instance recursion: small holonomic chains only");
+  const int li = blockIdx.x * 64 + threadIdx.x;
+  if (li >= *W.n_act) return;
+  const int b = W.act_idx[li];
+  if (W.status[b] != ST_ACTIVE) return;
+  const int N = M.N;
+  (void)B;
+  Reduced r = {0, 0, 0, 0, 0, 0, 0, 0, 1e300, 0, 0};
+  for (int k = 0; k < N; k++) {
+    r.f += W.part[IDX(P_F, k, b)];
+    r.th += W.part[IDX(P_TH, k, b)];
+    r.lgs += W.part[IDX(P_LOGS, k, b)];
+    r.rstat = fmax(r.rstat, W.part[IDX(P_RSTAT, k, b)]);
+    r.req = fmax(r.req, W.part[IDX(P_REQ, k, b)]);
+    r.rineq = fmax(r.rineq, W.part[IDX(P_RINEQ, k, b)]);
+    r.rcomp = fmax(r.rcomp, W.part[IDX(P_RCOMP, k, b)]);
+    r.sumc += W.part[IDX(P_SUMC, k, b)];
+    r.minc = fmin(r.minc, W.part[IDX(P_MINC, k, b)]);
+    r.badf += W.part[IDX(P_BAD, k, b)];
+    r.gphi += first ? 0.0 : W.gphi[(size_t)k * W.Bp + b];
+  }
+  Inst s;
+  inst_load(s, W, b);
+  bool usec = false;
+  const bool recurse = inst_decide<C>(M, s, r, first != 0, usec);
+  inst_store(s, W, b);
+  if (!recurse) return;
+  const double mu = s.mu, cwt = usec ? 1.0 : 0.0;
+  const double h = M.dt, h2 = 0.5 * M.dt * M.dt;
+  constexpr int NP2 = NX * (NX + 1) / 2;
+  constexpr int OFF_KFF = NW * NX, OFF_PT = NW * NX + NW, OFF_P = OFF_PT + NP2, OFF_RC = OFF_P + NX;
+  auto tri = [](int i, int j) __attribute__((always_inline)) {
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    return lo * NX - lo * (lo - 1) / 2 + (hi - lo);
+  };
+  // kind of a variable (0 q, 1 v, 2 u, 3 slack) and its joint: rows of [A | B]^T are (1, 0), (h, 1), (h2, h) on the
+  // (q+, v+) block rows
+  auto kind = [](int i) __attribute__((always_inline)) { return i < NQ ? 0 : (i < NX ? 1 : (i >= NX + NS ? 2 : 3)); };
+  auto joint = [](int i) __attribute__((always_inline)) { return i < NQ ? i : (i < NX ? i - NQ : (i >= NX + NS ? i - NX - NS : 0)); };
+  double P[NX][NX], pv[NX];
+#pragma unroll
+  for (int i = 0; i < NX; i++) {
+    pv[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NX; j++) P[i][j] = 0.0;
+  }
+  bool chol_ok = true;
+  const gdouble *const rb = (const gdouble *)(W.R + (size_t)b * N * C::RS);
+  gdouble *const kpb = (gdouble *)(W.KP + (size_t)b * N * W.kps);
+  for (int k = N - 1; k >= 0; k--) {
+    const gdouble *const rec = rb + (size_t)k * C::RS;
+    gdouble *const kpk = kpb + (size_t)k * W.kps;
+    const bool rec_cost = k < N - 1;
+    double rcv[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) rcv[j] = rec[C::R_RC + j];
+    // ---- dense stage block Q (NV x NV) and gradient q ------------------------------------------------------
+    double Q[NV][NV], q[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        double v = 0.0;
+        if (hi < NQ) {
+          const int t = lo * NQ - lo * (lo - 1) / 2 + (hi - lo);
+          v = rec[C::R_Q + t] - cwt * (C::CURV ? (double)rec[C::R_C + t] : 0.0);
+        } else if (lo == hi) {
+          v = rec[C::R_DG + (lo - NQ)];
+        } else if (NS > 0 && lo == NX) {
+          v = rec[C::R_CS + hi];
+        } else if (NS > 0 && hi == NX) {
+          v = rec[C::R_CS + lo];
+        }
+        const int ki = kind(i), kj = kind(j);
+        if (ki != 3 && kj != 3) {
+          const int ii = joint(i), jj = joint(j);
+          const double l1 = ki == 0 ? 1.0 : (ki == 1 ? h : h2), l2 = ki == 0 ? 0.0 : (ki == 1 ? 1.0 : h);
+          const double c1 = kj == 0 ? 1.0 : (kj == 1 ? h : h2), c2 = kj == 0 ? 0.0 : (kj == 1 ? 1.0 : h);
+          const double add = l1 * (c1 * P[ii][jj] + c2 * P[ii][NQ + jj]) + l2 * (c1 * P[NQ + ii][jj] + c2 * P[NQ + ii][NQ + jj]);
+          v += rec_cost ? add : 0.0;
+        }
+        Q[i][j] = v;
+      }
+    double Pc[NX];
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      double sacc = pv[i];
+#pragma unroll
+      for (int l = 0; l < NX; l++) sacc += P[i][l] * rcv[l];
+      Pc[i] = sacc;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      double v = rec[C::R_Q0 + i] - mu * rec[C::R_Q1 + i];
+      const int ki = kind(i);
+      if (ki != 3) {
+        const int ii = joint(i);
+        const double l1 = ki == 0 ? 1.0 : (ki == 1 ? h : h2), l2 = ki == 0 ? 0.0 : (ki == 1 ? 1.0 : h);
+        const double add = l1 * Pc[ii] + l2 * Pc[NQ + ii];
+        v += rec_cost ? add : 0.0;
+      }
+      q[i] = v;
+    }
+    // ---- Cholesky of Qww, gains ----------------------------------------------------------------------------------
+    double L[NW][NW], invd[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      double dg = Q[NX + j][NX + j];
+#pragma unroll
+      for (int l = 0; l < j; l++) dg -= L[j][l] * L[j][l];
+      if (!(dg > 0.0)) chol_ok = false;
+      double inv = __builtin_amdgcn_rsq(dg);
+      inv = inv * (1.5 - 0.5 * dg * inv * inv);
+      inv = inv * (1.5 - 0.5 * dg * inv * inv);
+      L[j][j] = dg * inv;
+      invd[j] = inv;
+#pragma unroll
+      for (int i = j + 1; i < NW; i++) {
+        double sacc = Q[NX + i][NX + j];
+#pragma unroll
+        for (int l = 0; l < j; l++) sacc -= L[i][l] * L[j][l];
+        L[i][j] = sacc * inv;
+      }
+    }
+    double K[NW][NX], kff[NW];
+#pragma unroll
+    for (int c = 0; c < NX; c++) {
+      double col[NW];
+#pragma unroll
+      for (int i = 0; i < NW; i++) col[i] = -Q[NX + i][c];
+      chol_solve<NW>(L, invd, col);
+#pragma unroll
+      for (int i = 0; i < NW; i++) K[i][c] = col[i];
+    }
+    {
+      double col[NW];
+#pragma unroll
+      for (int i = 0; i < NW; i++) col[i] = -q[NX + i];
+      chol_solve<NW>(L, invd, col);
+#pragma unroll
+      for (int i = 0; i < NW; i++) kff[i] = col[i];
+    }
+    // ---- cost-to-go P = sym(Qxx + Qxw K), p = qx + Qxw kff ----------------------------------------------------------
+    double Pa[NX][NX];
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+#pragma unroll
+      for (int j = 0; j < NX; j++) {
+        double a = Q[i][j];
+#pragma unroll
+        for (int l = 0; l < NW; l++) a += Q[i][NX + l] * K[l][j];
+        Pa[i][j] = a;
+      }
+      double a = q[i];
+#pragma unroll
+      for (int l = 0; l < NW; l++) a += Q[i][NX + l] * kff[l];
+      pv[i] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; i++)
+#pragma unroll
+      for (int j = 0; j < NX; j++) P[i][j] = 0.5 * (Pa[i][j] + Pa[j][i]);
+    // ---- gain image of the stage: K | kff | P (upper triangle) | p | rc ---------------------------------------------
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+#pragma unroll
+      for (int c = 0; c < NX; c++) kpk[i * NX + c] = K[i][c];
+      kpk[OFF_KFF + i] = kff[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+#pragma unroll
+      for (int j = i; j < NX; j++) kpk[OFF_PT + tri(i, j)] = P[i][j];
+      kpk[OFF_P + i] = pv[i];
+      kpk[OFF_RC + i] = rcv[i];
+    }
+  }
+  if (chol_ok) {
+    // ---- forward rollout: dw = kff + K dx, nu+ = p + P dx, dx+ = rc + [A | B][dx; dw] (closed form) --------------
+    double dx[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) dx[j] = 0.0;
+    const size_t SS = (size_t)N * W.Bp;
+    for (int k = 0; k < N; k++) {
+      const gdouble *const im = kpb + (size_t)k * W.kps;
+      double dw[NW];
+#pragma unroll
+      for (int i = 0; i < NW; i++) {
+        double sacc = im[OFF_KFF + i];
+#pragma unroll
+        for (int j = 0; j < NX; j++) sacc += im[i * NX + j] * dx[j];
+        dw[i] = sacc;
+      }
+      const size_t o = (size_t)k * W.Bp + b;
+#pragma unroll
+      for (int j = 0; j < NX; j++) W.dz[(size_t)j * SS + o] = dx[j];
+#pragma unroll
+      for (int i = 0; i < NW; i++) W.dz[(size_t)(NX + i) * SS + o] = dw[i];
+      if (k >= 1) {
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+          double sacc = im[OFF_P + i];
+#pragma unroll
+          for (int j = 0; j < NX; j++) sacc += im[OFF_PT + tri(i, j)] * dx[j];
+          W.nunew[(size_t)i * SS + o] = sacc;
+        }
+      }
+      if (k < N - 1) {
+        double dxn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+          const bool isq = i < NQ;
+          double sacc = im[OFF_RC + i];
+          sacc += dx[i];
+          sacc += (isq ? h : 0.0) * dx[isq ? NQ + i : i];
+          sacc += (isq ? h2 : h) * dw[NS + (isq ? i : i - NQ)];
+          dxn[i] = sacc;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; i++) dx[i] = dxn[i];
+      }
+    }
+  }
+  // = inst_after_recursion on the stored words
+  if (!chol_ok) {
+    if (usec) { W.redo[b] = 1; W.force_gn[b] = 1; W.usedc[b] = 0; }
+    else W.status[b] = -5;
+  } else {
+    W.usedc[b] = usec ? 1 : 0;
+    W.newstep[b] = 1;
+    W.amin_p[b] = (unsigned long long)__double_as_longlong(1.0);
+    W.amin_d[b] = (unsigned long long)__double_as_longlong(1.0);
+  }
+}
+
+// ===========================================================================
 // k_step: slack / multiplier steps and step-length partials, stage parallel
 // ===========================================================================
 // What one lane of the step kernel addresses (same convention as SweepIO).
@@ -3404,6 +3656,7 @@ struct rmpc_handle {
   int duals_B = 0;
   int spec = -1;        // generated view whose tables equal this descriptor's (rmpc_spec_gen.hpp), -1: runtime tables
   bool fused = false;   // this model runs the fused kernel (small models, N <= 32); the pass kernels otherwise
+  int ric_lane = 1;       // lane-per-instance recursion of the pass kernels: 0 never, 1 large lists, 2 always (RMPC_RIC_LANE)
   int fused_grid = 1024;  // wavefronts the chip holds at one per SIMD (4 x compute units): grid of a fused launch
   FusedWs F;
   int *h_passes = nullptr;  // pinned
@@ -3886,6 +4139,13 @@ static int launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hip
   if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C, V>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B, first,
                                            (first && h->warm_mode && h->have_duals) ? 1 : 0);
   else if (which == K_RICCATI) {
+    if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN && C::NQ <= 3) {
+      // lane-per-instance recursion for large lists (h->ric_lane: 0 never, 1 from kLaneMin instances on, 2 always)
+      if (h->ric_lane == 2 || (h->ric_lane == 1 && B >= kLaneMin)) {
+        hipLaunchKernelGGL((k_riccati_lane<C>), dim3((B + 63) / 64), dim3(64), 0, st, h->M, ph.W, B, first);
+        return 0;
+      }
+    }
     if (C::IPB > 1 && B >= kGroupedMin)
     {
       constexpr int per_block = C::IPB * (64 / C::RIC_LPI);   // instances per block
@@ -4272,6 +4532,7 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_active, sizeof(int), hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_passes, sizeof(int), hipHostMallocDefault);
   if (e != hipSuccess) { rmpc_destroy(h); return fail(std::string("stream / pinned word: ") + hipGetErrorString(e)); }
+  if (const char *rl = getenv("RMPC_RIC_LANE")) h->ric_lane = atoi(rl);   // (development switch)
   h->env_no_migrate = getenv("RMPC_NO_MIGRATE") != nullptr;
   h->env_no_order = getenv("RMPC_NO_ORDER") != nullptr;   // (development switch: fused launches in index order)
   h->env_dump_hist = getenv("RMPC_DUMP_HIST") != nullptr;

@@ -13,6 +13,8 @@ sc = make_scenario(name, B=B, seed=1)
 dev = torch.device("cuda", 0)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 s = Solver(sc.desc, max_batch=B)
+if os.environ.get("DEV_BUDGET"):   # only the first passes of a solve: every instance still iterates in each launch
+    s.set_pass_budget(int(os.environ["DEV_BUDGET"]))
 xi, x0, pa = t(sc.xinit), t(sc.x0), t(sc.params)
 N, nv = sc.desc["N"], s.nvar
 z = torch.empty((B, N, nv), dtype=torch.float64, device=dev); ef = torch.empty(B, dtype=torch.int32, device=dev)
