@@ -41,6 +41,31 @@
 #include "rmpc_model.hpp"
 #include "rmpc_spec_gen.hpp"   // generated views of the shipped configurations (scripts/gen_specs.py)
 
+// ---- kernel variants and translation units ---------------------------------------------------------------------
+// One kernel variant per robot family and size: X(id, robot kind, n, ns).  ids 0 .. 5 are the shipped configurations
+// (point robot, panda, boxer, each without / with the slack variable); 6 .. 9 further holonomic chains (mpcBase.py:52-55:
+// n = fk.n() of whatever URDF chain the YAML names), the sizes the test suite can build from the shipped URDFs
+// (tests: chain2, chain4, chain5, chain6).  Another size is one more line here, one more #if block below
+// (instantiation list) and one more bit in __graft_entry__.TU_MASKS.
+#define RMPC_VARIANTS(X)                                                                                                  \
+  X(0, RMPC_ROBOT_CHAIN, 3, 0) X(1, RMPC_ROBOT_CHAIN, 3, 1) X(2, RMPC_ROBOT_CHAIN, 7, 0) X(3, RMPC_ROBOT_CHAIN, 7, 1)    \
+  X(4, RMPC_ROBOT_DIFFDRIVE, 3, 0) X(5, RMPC_ROBOT_DIFFDRIVE, 3, 1) X(6, RMPC_ROBOT_CHAIN, 2, 0) X(7, RMPC_ROBOT_CHAIN, 4, 0) \
+  X(8, RMPC_ROBOT_CHAIN, 5, 0) X(9, RMPC_ROBOT_CHAIN, 6, 0)
+// The library is built from this one source compiled several times in parallel (__graft_entry__.build: one translation
+// unit per group of variants, minutes of compile time otherwise): RMPC_DEV_VARIANTS is the bit mask of the variants whose
+// kernels THIS translation unit instantiates, RMPC_ALL_VARIANTS the mask of the variants the library holds (what the
+// dispatch offers), RMPC_TU_MAIN says whether this unit carries the host side and the variant-independent kernels.
+// A plain one-file build (hipcc rmpc_kernels.hip) has all three at their defaults: everything in one unit.
+#ifndef RMPC_DEV_VARIANTS
+#define RMPC_DEV_VARIANTS 0x3ff
+#endif
+#ifndef RMPC_ALL_VARIANTS
+#define RMPC_ALL_VARIANTS RMPC_DEV_VARIANTS
+#endif
+#ifndef RMPC_TU_MAIN
+#define RMPC_TU_MAIN 1
+#endif
+
 namespace rmpc {
 
 // solver constants (DESIGN.md, section "Algorithm")
@@ -110,6 +135,7 @@ struct Ws {
 #define IDXL(slot) ((size_t)(slot) * SS + loff)
 #define IDXL1(slot) ((size_t)(slot) * SS + loff1)
 
+#if RMPC_TU_MAIN
 // ===========================================================================
 // pack / unpack: instance-major ABI layout <-> batch-minor SoA (LDS transpose)
 // ===========================================================================
@@ -140,6 +166,8 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ in, dou
   }
 }
 
+#endif  // RMPC_TU_MAIN
+
 // stage-0 state := xinit (mpcModel.py:108 xinitidx), per-instance state reset
 __device__ __forceinline__ double warm_mu(double wmu, double mu0) {
   double mu = kWarmKappa * wmu;
@@ -148,6 +176,7 @@ __device__ __forceinline__ double warm_mu(double wmu, double mu0) {
   return mu;
 }
 
+#if RMPC_TU_MAIN
 __global__ __launch_bounds__(256) void k_init(Ws W, const double *__restrict__ xinit, int B, int nx, double mu0, int warm) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
@@ -340,6 +369,8 @@ __global__ __launch_bounds__(64) void k_migrate(const Ws S, const Ws D, int n, i
     if (li == 0) *D.n_act = n;
   }
 }
+
+#endif  // RMPC_TU_MAIN
 
 // 1/x for normal positive x: hardware estimate + two Newton steps (about 1 ulp; a full fp64 division costs three
 // times as many instructions and the sweep performs one or two per constraint row)
@@ -3360,6 +3391,7 @@ __global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTabl
 #endif
 }
 
+#if RMPC_TU_MAIN
 // Launch order of a warm-started fused launch: the instances sorted by the passes of their previous solve, longest
 // first (counting sort, one block; the order inside a bucket is whatever the atomics give -- it changes which
 // instances share a wavefront, never what an instance computes).
@@ -3385,6 +3417,8 @@ __global__ __launch_bounds__(1024) void k_order(const int *__restrict__ key, int
     order[atomicAdd(&cnt[255 - kq], 1)] = b;
   }
 }
+
+#endif  // RMPC_TU_MAIN
 
 // ===========================================================================
 // Scene packing and closed-loop advance: device
@@ -3570,6 +3604,7 @@ __global__ __launch_bounds__(256) void k_retarget(const DevModel M, const DevTab
   dwell[b] = dw;
 }
 
+#if RMPC_TU_MAIN
 // ===========================================================================
 // Free-space decomposition: lidar point cloud -> at most K half-planes
 // around a seed point, one lane per (instance, stage) seed.  Greedy rule of the reference
@@ -3621,6 +3656,8 @@ __global__ __launch_bounds__(256) void k_fsd(const double *__restrict__ points, 
   }
 }
 
+#endif  // RMPC_TU_MAIN
+
 }  // namespace rmpc
 
 // ===========================================================================
@@ -3628,8 +3665,8 @@ __global__ __launch_bounds__(256) void k_fsd(const double *__restrict__ points, 
 // ===========================================================================
 using namespace rmpc;
 
-static thread_local std::string g_err;
-static int fail(const std::string &m) {
+inline thread_local std::string g_err;   // (one object for all translation units of the library)
+inline int fail(const std::string &m) {
   g_err = m;
   return -1;
 }
@@ -3690,6 +3727,166 @@ struct rmpc_handle {
   // debugging switches, read once at rmpc_create (never set by the product code)
   bool env_no_migrate = false, env_dump_hist = false, env_no_order = false;
 };
+
+// ---- per-variant launchers -----------------------------------------------------------------------------------------
+// Function templates that reference the kernels of ONE variant: instantiated in the translation unit that builds the
+// variant (explicit instantiations below), only declared (extern template) in the others.
+// The workspace the passes currently run in: the batch's own, or the compact one after migration
+// (B = number of columns in use).
+struct Phase {
+  Ws W;
+  int B;
+};
+constexpr int variant_id(int R, int NQ, int NS) {
+#define RMPC_VID(ID, r, nq, ns) \
+  if (R == r && NQ == nq && NS == ns) return ID;
+  RMPC_VARIANTS(RMPC_VID)
+#undef RMPC_VID
+  return -1;
+}
+template <int R, int NQ, int NS>
+constexpr bool variant_built() {       // kernels of the variant are instantiated in this translation unit
+  return variant_id(R, NQ, NS) >= 0 && ((RMPC_DEV_VARIANTS >> variant_id(R, NQ, NS)) & 1);
+}
+template <int R, int NQ, int NS>
+constexpr bool variant_available() {   // the library holds the variant (possibly in another translation unit)
+  return variant_id(R, NQ, NS) >= 0 && ((RMPC_ALL_VARIANTS >> variant_id(R, NQ, NS)) & 1);
+}
+
+template <class C, class V>
+int launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hipStream_t st, int which) {
+  const int B = ph.B;
+  const int lanes = ph.W.Bp * h->M.N;
+  if (ph.W.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
+  if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C, V>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B, first,
+                                           (first && h->warm_mode && h->have_duals) ? 1 : 0);
+  else if (which == K_RICCATI) {
+    if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN && C::NQ <= 3) {
+      // lane-per-instance recursion for large lists (h->ric_lane: 0 never, 1 from kLaneMin instances on, 2 always)
+      if (h->ric_lane == 2 || (h->ric_lane == 1 && B >= kLaneMin)) {
+        hipLaunchKernelGGL((k_riccati_lane<C>), dim3((B + 63) / 64), dim3(64), 0, st, h->M, ph.W, B, first);
+        return 0;
+      }
+    }
+    if (C::IPB > 1 && B >= kGroupedMin)
+    {
+      constexpr int per_block = C::IPB * (64 / C::RIC_LPI);   // instances per block
+      hipLaunchKernelGGL((k_riccati<C, C::IPB>), dim3((B + per_block - 1) / per_block), dim3(64 * C::IPB), 0, st, h->M, ph.W, B, first, pass);
+    }
+    const int tail_blocks = (C::IPB == 1 || B < kGroupedMin) ? B : kGroupedMin;
+    hipLaunchKernelGGL((k_riccati<C, 1>), dim3(tail_blocks), dim3(64), 0, st, h->M, ph.W, B, first, pass);
+  }
+  else hipLaunchKernelGGL((k_step<C, V>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B);
+  return 0;
+}
+
+template <class C, class V>
+int launch_fused_t(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
+                          double *d_zout, int *d_exit, int *d_iters, double *d_kkt, double *d_obj, hipStream_t st, int cap) {
+  const int warm = (h->warm_mode && h->have_duals) ? 1 : 0;
+  if (h->F.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
+  // closed loop: the previous solve of this batch tells which instances take long (k_fused: launch order)
+  const int use_order = (warm && !h->env_no_order) ? 1 : 0;
+  // the grid is the chip (one wavefront per SIMD: __launch_bounds__(64, 1)), the batch is a queue its halves drain
+  const int pairs = (B + 1) / 2;
+  const int grid = pairs < h->fused_grid ? pairs : h->fused_grid;
+  hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, V>), dim3(grid), dim3(64), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
+                     d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm, use_order);
+  return 0;
+}
+template <class C>
+int launch_advance(rmpc_handle *h, int B, const double *d_z_prev, const int *ef, double *d_xinit, double *d_x0, int previous_plan,
+                   hipStream_t st) {
+  hipLaunchKernelGGL((k_advance<C>), dim3((B + kAdvanceIB - 1) / kAdvanceIB), dim3(256), 0, st, h->M, d_z_prev, d_xinit, d_x0, B,
+                     previous_plan, ef);
+  return 0;
+}
+template <class C>
+int launch_retarget(rmpc_handle *h, int B, double *d_xinit, double *d_x0, const int *ef, double *d_goal, const double *d_goal_pool,
+                    int pool_len, int *d_cursor, int *d_dwell, const double *d_x_start, double tol, int max_dwell, int *d_counts,
+                    const int *d_iters, double *wmu, double wmu_regoal, hipStream_t st) {
+  hipLaunchKernelGGL((k_retarget<C>), dim3((B + 255) / 256), dim3(256), 0, st, h->M, h->d_T, B, d_xinit, d_x0, ef, d_goal, d_goal_pool,
+                     pool_len, d_cursor, d_dwell, d_x_start, tol, max_dwell, d_counts, d_iters, wmu, wmu_regoal);
+  return 0;
+}
+
+// Explicit instantiations for the variants of this translation unit, extern declarations for the variants built in
+// another one (the preprocessor cannot pick the keyword inside RMPC_VARIANTS: one #if per variant id; the list must
+// follow RMPC_VARIANTS, static_assert below).  Generated views are instantiated implicitly by the dispatch of the main
+// unit: a view is offered only when its variant is built there.
+#define RMPC_SIG_PASS (rmpc_handle *, const Phase &, int, int, hipStream_t, int)
+#define RMPC_SIG_FUSED (rmpc_handle *, int, const double *, const double *, const double *, double *, int *, int *, double *, double *, hipStream_t, int)
+#define RMPC_SIG_ADV (rmpc_handle *, int, const double *, const int *, double *, double *, int, hipStream_t)
+#define RMPC_SIG_RET (rmpc_handle *, int, double *, double *, const int *, double *, const double *, int, int *, int *, const double *, double, int, int *, const int *, double *, double, hipStream_t)
+#define RMPC_INST(KW, R, NQ, NS)                                      \
+  KW int launch_pass<Cfg<R, NQ, NS>, RtView> RMPC_SIG_PASS;           \
+  KW int launch_advance<Cfg<R, NQ, NS>> RMPC_SIG_ADV;                 \
+  KW int launch_retarget<Cfg<R, NQ, NS>> RMPC_SIG_RET;
+#define RMPC_INST_F(KW, R, NQ, NS) KW int launch_fused_t<Cfg<R, NQ, NS>, RtView> RMPC_SIG_FUSED;
+static_assert(variant_id(RMPC_ROBOT_CHAIN, 3, 0) == 0, "instantiation list out of step with RMPC_VARIANTS");
+#if (RMPC_DEV_VARIANTS >> 0) & 1
+RMPC_INST(template, RMPC_ROBOT_CHAIN, 3, 0) RMPC_INST_F(template, RMPC_ROBOT_CHAIN, 3, 0)
+#elif (RMPC_ALL_VARIANTS >> 0) & 1
+RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 3, 0) RMPC_INST_F(extern template, RMPC_ROBOT_CHAIN, 3, 0)
+#endif
+static_assert(variant_id(RMPC_ROBOT_CHAIN, 3, 1) == 1, "instantiation list out of step with RMPC_VARIANTS");
+#if (RMPC_DEV_VARIANTS >> 1) & 1
+RMPC_INST(template, RMPC_ROBOT_CHAIN, 3, 1) RMPC_INST_F(template, RMPC_ROBOT_CHAIN, 3, 1)
+#elif (RMPC_ALL_VARIANTS >> 1) & 1
+RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 3, 1) RMPC_INST_F(extern template, RMPC_ROBOT_CHAIN, 3, 1)
+#endif
+static_assert(variant_id(RMPC_ROBOT_CHAIN, 7, 0) == 2, "instantiation list out of step with RMPC_VARIANTS");
+#if (RMPC_DEV_VARIANTS >> 2) & 1
+RMPC_INST(template, RMPC_ROBOT_CHAIN, 7, 0)
+#elif (RMPC_ALL_VARIANTS >> 2) & 1
+RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 7, 0)
+#endif
+static_assert(variant_id(RMPC_ROBOT_CHAIN, 7, 1) == 3, "instantiation list out of step with RMPC_VARIANTS");
+#if (RMPC_DEV_VARIANTS >> 3) & 1
+RMPC_INST(template, RMPC_ROBOT_CHAIN, 7, 1)
+#elif (RMPC_ALL_VARIANTS >> 3) & 1
+RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 7, 1)
+#endif
+static_assert(variant_id(RMPC_ROBOT_DIFFDRIVE, 3, 0) == 4, "instantiation list out of step with RMPC_VARIANTS");
+#if (RMPC_DEV_VARIANTS >> 4) & 1
+RMPC_INST(template, RMPC_ROBOT_DIFFDRIVE, 3, 0) RMPC_INST_F(template, RMPC_ROBOT_DIFFDRIVE, 3, 0)
+#elif (RMPC_ALL_VARIANTS >> 4) & 1
+RMPC_INST(extern template, RMPC_ROBOT_DIFFDRIVE, 3, 0) RMPC_INST_F(extern template, RMPC_ROBOT_DIFFDRIVE, 3, 0)
+#endif
+static_assert(variant_id(RMPC_ROBOT_DIFFDRIVE, 3, 1) == 5, "instantiation list out of step with RMPC_VARIANTS");
+#if (RMPC_DEV_VARIANTS >> 5) & 1
+RMPC_INST(template, RMPC_ROBOT_DIFFDRIVE, 3, 1) RMPC_INST_F(template, RMPC_ROBOT_DIFFDRIVE, 3, 1)
+#elif (RMPC_ALL_VARIANTS >> 5) & 1
+RMPC_INST(extern template, RMPC_ROBOT_DIFFDRIVE, 3, 1) RMPC_INST_F(extern template, RMPC_ROBOT_DIFFDRIVE, 3, 1)
+#endif
+static_assert(variant_id(RMPC_ROBOT_CHAIN, 2, 0) == 6, "instantiation list out of step with RMPC_VARIANTS");
+#if (RMPC_DEV_VARIANTS >> 6) & 1
+RMPC_INST(template, RMPC_ROBOT_CHAIN, 2, 0) RMPC_INST_F(template, RMPC_ROBOT_CHAIN, 2, 0)
+#elif (RMPC_ALL_VARIANTS >> 6) & 1
+RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 2, 0) RMPC_INST_F(extern template, RMPC_ROBOT_CHAIN, 2, 0)
+#endif
+static_assert(variant_id(RMPC_ROBOT_CHAIN, 4, 0) == 7, "instantiation list out of step with RMPC_VARIANTS");
+#if (RMPC_DEV_VARIANTS >> 7) & 1
+RMPC_INST(template, RMPC_ROBOT_CHAIN, 4, 0)
+#elif (RMPC_ALL_VARIANTS >> 7) & 1
+RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 4, 0)
+#endif
+static_assert(variant_id(RMPC_ROBOT_CHAIN, 5, 0) == 8, "instantiation list out of step with RMPC_VARIANTS");
+#if (RMPC_DEV_VARIANTS >> 8) & 1
+RMPC_INST(template, RMPC_ROBOT_CHAIN, 5, 0)
+#elif (RMPC_ALL_VARIANTS >> 8) & 1
+RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 5, 0)
+#endif
+static_assert(variant_id(RMPC_ROBOT_CHAIN, 6, 0) == 9, "instantiation list out of step with RMPC_VARIANTS");
+#if (RMPC_DEV_VARIANTS >> 9) & 1
+RMPC_INST(template, RMPC_ROBOT_CHAIN, 6, 0)
+#elif (RMPC_ALL_VARIANTS >> 9) & 1
+RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 6, 0)
+#endif
+#undef RMPC_INST
+#undef RMPC_INST_F
+
+#if RMPC_TU_MAIN
 
 // Row tables in device memory (DevTables): kinematic slots with their FK rows, and the
 // single-variable rows grouped by variable.
@@ -3753,13 +3950,12 @@ static int build_tables(const rmpc_desc &d, const DevModel &M, DevTables &T, std
 }
 
 static int variant_of(const rmpc_desc &d) {
-  // 0..5: (chain n=3, chain n=7, diffdrive) x (ns = 0, 1)
-  int base;
-  if (d.robot == RMPC_ROBOT_CHAIN && d.n == 3) base = 0;
-  else if (d.robot == RMPC_ROBOT_CHAIN && d.n == 7) base = 1;
-  else if (d.robot == RMPC_ROBOT_DIFFDRIVE && d.n == 3) base = 2;
-  else return -1;
-  return base * 2 + (d.ns ? 1 : 0);
+  // id of the kernel variant (RMPC_VARIANTS) this library holds for the robot, -1: none
+#define RMPC_VO(ID, R, NQ, NS) \
+  if (((RMPC_ALL_VARIANTS >> ID) & 1) && d.robot == R && d.n == NQ && (d.ns ? 1 : 0) == NS) return ID;
+  RMPC_VARIANTS(RMPC_VO)
+#undef RMPC_VO
+  return -1;
 }
 
 static int build_model(const rmpc_desc &d, DevModel &M, std::string &err) {
@@ -4007,8 +4203,10 @@ static bool spec_matches(const rmpc_desc &d, const DevModel &M, const DevTables 
   return ok;
 }
 static int find_spec(const rmpc_desc &d, const DevModel &M, const DevTables &T) {
-#define RMPC_X(ID, S, R, NQ, NS) \
-  if (spec_matches<S>(d, M, T)) return ID;
+#define RMPC_X(ID, S, R, NQ, NS)                 \
+  if constexpr (variant_built<R, NQ, NS>()) {    \
+    if (spec_matches<S>(d, M, T)) return ID;     \
+  }
   RMPC_SPECS(RMPC_X)
 #undef RMPC_X
   return -1;
@@ -4124,50 +4322,6 @@ static void fill_lane_bytes(rmpc_handle *h, int B) {
   h->lane_bytes[K_FUSED] = 8 * ((int64_t)M.nx + 2 * (int64_t)M.N * M.nv + (int64_t)M.N * M.npar) + 24;
 }
 
-// The workspace the passes currently run in: the batch's own, or the compact one after migration
-// (B = number of columns in use).
-struct Phase {
-  Ws W;
-  int B;
-};
-
-template <class C, class V>
-static int launch_pass(rmpc_handle *h, const Phase &ph, int first, int pass, hipStream_t st, int which) {
-  const int B = ph.B;
-  const int lanes = ph.W.Bp * h->M.N;
-  if (ph.W.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
-  if (which == K_SWEEP) hipLaunchKernelGGL((k_sweep<C, V>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B, first,
-                                           (first && h->warm_mode && h->have_duals) ? 1 : 0);
-  else if (which == K_RICCATI) {
-    if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN && C::NQ <= 3) {
-      // lane-per-instance recursion for large lists (h->ric_lane: 0 never, 1 from kLaneMin instances on, 2 always)
-      if (h->ric_lane == 2 || (h->ric_lane == 1 && B >= kLaneMin)) {
-        hipLaunchKernelGGL((k_riccati_lane<C>), dim3((B + 63) / 64), dim3(64), 0, st, h->M, ph.W, B, first);
-        return 0;
-      }
-    }
-    if (C::IPB > 1 && B >= kGroupedMin)
-    {
-      constexpr int per_block = C::IPB * (64 / C::RIC_LPI);   // instances per block
-      hipLaunchKernelGGL((k_riccati<C, C::IPB>), dim3((B + per_block - 1) / per_block), dim3(64 * C::IPB), 0, st, h->M, ph.W, B, first, pass);
-    }
-    const int tail_blocks = (C::IPB == 1 || B < kGroupedMin) ? B : kGroupedMin;
-    hipLaunchKernelGGL((k_riccati<C, 1>), dim3(tail_blocks), dim3(64), 0, st, h->M, ph.W, B, first, pass);
-  }
-  else hipLaunchKernelGGL((k_step<C, V>), dim3((lanes + kSweepBlock - 1) / kSweepBlock), dim3(kSweepBlock), 0, st, h->M, h->d_T, ph.W, B);
-  return 0;
-}
-
-// Development builds may restrict the kernel variants that are instantiated (-DRMPC_DEV_VARIANTS=<bit mask over
-// variant_of()>: a full build takes minutes); the product build has them all.
-#ifndef RMPC_DEV_VARIANTS
-#define RMPC_DEV_VARIANTS 0x3f
-#endif
-template <int R, int NQ, int NS>
-constexpr bool variant_built() {
-  return (RMPC_DEV_VARIANTS >> ((R == RMPC_ROBOT_CHAIN ? (NQ == 3 ? 0 : 1) : 2) * 2 + (NS ? 1 : 0))) & 1;
-}
-
 static int launch_variant(rmpc_handle *h, const Phase &ph, int first, int pass, hipStream_t st, int which) {
   // a generated view when the descriptor's tables equal one (rmpc_create), the runtime tables otherwise
 #define RMPC_X(ID, S, R, NQ, NS)                                                            \
@@ -4177,11 +4331,10 @@ static int launch_variant(rmpc_handle *h, const Phase &ph, int first, int pass, 
   RMPC_SPECS(RMPC_X)
 #undef RMPC_X
 #define RMPC_V(ID, R, NQ, NS)                                                                         \
-  if constexpr (variant_built<R, NQ, NS>()) {                                                         \
+  if constexpr (variant_available<R, NQ, NS>()) {                                                     \
     if (h->variant == ID) return launch_pass<Cfg<R, NQ, NS>, RtView>(h, ph, first, pass, st, which);  \
   }
-  RMPC_V(0, RMPC_ROBOT_CHAIN, 3, 0) RMPC_V(1, RMPC_ROBOT_CHAIN, 3, 1) RMPC_V(2, RMPC_ROBOT_CHAIN, 7, 0)
-  RMPC_V(3, RMPC_ROBOT_CHAIN, 7, 1) RMPC_V(4, RMPC_ROBOT_DIFFDRIVE, 3, 0) RMPC_V(5, RMPC_ROBOT_DIFFDRIVE, 3, 1)
+  RMPC_VARIANTS(RMPC_V)
 #undef RMPC_V
   return fail("no kernel variant (built with RMPC_DEV_VARIANTS?)");
 }
@@ -4260,44 +4413,39 @@ static bool fused_supported(int variant, const DevModel &M) {
   // -- against ~480 k for the four pass kernels.  Restructuring the arm's recursion like the chain's (records straight
   // into registers, three ordering points per stage) changed nothing either (6.8 vs 7.0 ms per batch): it is bound by
   // the 7 x 7 factorisation and the cost-to-go update, not by its ordering points.
-  return (variant == 0 || variant == 1 || variant == 4 || variant == 5) && M.N <= kFusedStages;
+  bool ok = false;
+#define RMPC_FS(ID, R, NQ, NS) \
+  if (variant == ID) ok = Cfg<R, NQ, NS>::FUSED_OK;
+  RMPC_VARIANTS(RMPC_FS)
+#undef RMPC_FS
+  return ok && M.N <= kFusedStages;
 }
 
-template <class C, class V>
-static int launch_fused_t(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
-                          double *d_zout, int *d_exit, int *d_iters, double *d_kkt, double *d_obj, hipStream_t st, int cap) {
-  const int warm = (h->warm_mode && h->have_duals) ? 1 : 0;
-  if (h->F.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
-  // closed loop: the previous solve of this batch tells which instances take long (k_fused: launch order)
-  const int use_order = (warm && !h->env_no_order) ? 1 : 0;
-  // the grid is the chip (one wavefront per SIMD: __launch_bounds__(64, 1)), the batch is a queue its halves drain
-  const int pairs = (B + 1) / 2;
-  const int grid = pairs < h->fused_grid ? pairs : h->fused_grid;
-  hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, V>), dim3(grid), dim3(64), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
-                     d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm, use_order);
-  // the order of the NEXT warm-started launch, right behind this one (in front of it the little kernel would wait
-  // for a free SIMD whenever another handle's fused launch fills the chip: 130 us in the fleet loop)
-  if (h->warm_mode && !h->env_no_order)
-    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const int *)h->F.lastp, h->F.order, B);
-  return 0;
-}
 static int launch_fused(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
                         double *d_zout, int *d_exit, int *d_iters, double *d_kkt, double *d_obj, hipStream_t st, int cap) {
+  int rc = -2;
 #define RMPC_X(ID, S, R, NQ, NS)                                                                                    \
   if constexpr (Cfg<R, NQ, NS>::FUSED_OK && variant_built<R, NQ, NS>()) {                                           \
-    if (h->spec == ID)                                                                                              \
-      return launch_fused_t<Cfg<R, NQ, NS>, S>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap); \
+    if (rc == -2 && h->spec == ID)                                                                                  \
+      rc = launch_fused_t<Cfg<R, NQ, NS>, S>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap); \
   }
   RMPC_SPECS(RMPC_X)
 #undef RMPC_X
 #define RMPC_V(ID, R, NQ, NS)                                                                                       \
-  if constexpr (variant_built<R, NQ, NS>()) {                                                                       \
-    if (h->variant == ID)                                                                                           \
-      return launch_fused_t<Cfg<R, NQ, NS>, RtView>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap); \
+  if constexpr (Cfg<R, NQ, NS>::FUSED_OK && variant_available<R, NQ, NS>()) {                                       \
+    if (rc == -2 && h->variant == ID)                                                                               \
+      rc = launch_fused_t<Cfg<R, NQ, NS>, RtView>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap); \
   }
-  RMPC_V(0, RMPC_ROBOT_CHAIN, 3, 0) RMPC_V(1, RMPC_ROBOT_CHAIN, 3, 1)
-  RMPC_V(4, RMPC_ROBOT_DIFFDRIVE, 3, 0) RMPC_V(5, RMPC_ROBOT_DIFFDRIVE, 3, 1)
+  RMPC_VARIANTS(RMPC_V)
 #undef RMPC_V
+  if (rc == 0) {
+    // the order of the NEXT warm-started launch, right behind this one (in front of it the little kernel would wait
+    // for a free SIMD whenever another handle's fused launch fills the chip: 130 us in the fleet loop)
+    if (h->warm_mode && !h->env_no_order)
+      hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const int *)h->F.lastp, h->F.order, B);
+    return 0;
+  }
+  if (rc != -2) return rc;
   return fail("no fused kernel for this model");
 }
 
@@ -4482,7 +4630,7 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   if (build_model(*desc, h->M, err) != 0) { delete h; return fail("invalid descriptor: " + err); }
   if (build_tables(*desc, h->M, h->T, err) != 0) { delete h; return fail("invalid descriptor: " + err); }
   h->variant = variant_of(*desc);
-  if (h->variant < 0) { delete h; return fail("no kernel variant for this robot (supported: chain n=3, chain n=7, diff-drive n=3)"); }
+  if (h->variant < 0) { delete h; return fail("no kernel variant for this robot (built: holonomic chains n = 2 .. 7, with the slack variable n = 3 and 7; diff-drive base without an arm)"); }
   // Generated views (rmpc_spec_gen.hpp: the point-robot configurations).  Measured in round 2: with the chip full the
   // throughput is the same as with the runtime tables (1.60-1.65 M solves/s either way: the fused kernel is bound by
   // the traffic of the iterate, not by its instruction count), one batch alone is 6 % faster (4.42 vs 4.69 ms: the
@@ -4669,16 +4817,13 @@ int rmpc_advance_device_flags(rmpc_handle *h, int B, const double *d_z_prev, con
   if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;   // NULL: the legacy null stream, ordered with the caller's default-stream work
-  const dim3 g((B + kAdvanceIB - 1) / kAdvanceIB), t(256);
   const int *ef = (const int *)d_exitflag;
-  switch (h->variant) {
-    case 0: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 3, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan, ef); break;
-    case 1: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 3, 1>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan, ef); break;
-    case 2: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 7, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan, ef); break;
-    case 3: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_CHAIN, 7, 1>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan, ef); break;
-    case 4: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 0>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan, ef); break;
-    case 5: hipLaunchKernelGGL((k_advance<Cfg<RMPC_ROBOT_DIFFDRIVE, 3, 1>>), g, t, 0, st, h->M, d_z_prev, d_xinit, d_x0, B, previous_plan, ef); break;
+#define RMPC_AD(ID, R, NQ, NS)                                                                                       \
+  if constexpr (variant_available<R, NQ, NS>()) {                                                                    \
+    if (h->variant == ID) launch_advance<Cfg<R, NQ, NS>>(h, B, d_z_prev, ef, d_xinit, d_x0, previous_plan, st);      \
   }
+  RMPC_VARIANTS(RMPC_AD)
+#undef RMPC_AD
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -4697,17 +4842,16 @@ int rmpc_retarget_device(rmpc_handle *h, int B, double *d_xinit, double *d_x0, c
   if (!h->desc.has_goal) return fail("the model has no GoalReaching objective");
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
-  const dim3 g((B + 255) / 256), t(256);
   const int *ef = (const int *)d_exitflag;
   double *const wmu = h->warm_mode ? (h->fused ? h->F.wmu : h->W.wmu) : nullptr;
   const double wmu_regoal = mu_regoal > 0.0 ? mu_regoal / kWarmKappa : 0.0;
 #define RMPC_RT(ID, R, NQ, NS)                                                                                              \
-  case ID: hipLaunchKernelGGL((k_retarget<Cfg<R, NQ, NS>>), g, t, 0, st, h->M, h->d_T, B, d_xinit, d_x0, ef, d_goal, d_goal_pool, \
-                              pool_len, (int *)d_cursor, (int *)d_dwell, d_x_start, tol, max_dwell, (int *)d_counts, (const int *)d_iters, wmu, wmu_regoal); break;
-  switch (h->variant) {
-    RMPC_RT(0, RMPC_ROBOT_CHAIN, 3, 0) RMPC_RT(1, RMPC_ROBOT_CHAIN, 3, 1) RMPC_RT(2, RMPC_ROBOT_CHAIN, 7, 0)
-    RMPC_RT(3, RMPC_ROBOT_CHAIN, 7, 1) RMPC_RT(4, RMPC_ROBOT_DIFFDRIVE, 3, 0) RMPC_RT(5, RMPC_ROBOT_DIFFDRIVE, 3, 1)
+  if constexpr (variant_available<R, NQ, NS>()) {                                                                           \
+    if (h->variant == ID)                                                                                                   \
+      launch_retarget<Cfg<R, NQ, NS>>(h, B, d_xinit, d_x0, ef, d_goal, d_goal_pool, pool_len, (int *)d_cursor, (int *)d_dwell, \
+                                      d_x_start, tol, max_dwell, (int *)d_counts, (const int *)d_iters, wmu, wmu_regoal, st); \
   }
+  RMPC_VARIANTS(RMPC_RT)
 #undef RMPC_RT
   HIPCHK(hipGetLastError());
   return 0;
@@ -4901,3 +5045,4 @@ int rmpc_debug_sweep(rmpc_handle *h, int B, const double *xinit, const double *x
 }
 
 }  // extern "C"
+#endif  // RMPC_TU_MAIN

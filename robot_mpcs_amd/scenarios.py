@@ -38,6 +38,12 @@ CONFIG_FILES = {
     "wc_boxer": "wc_boxerMpc.yaml",
     "wc_boxer_slack": "wc_boxerSlackMpc.yaml",
     "wc_panda": "wc_pandaMpc.yaml",
+    # test configs: kernel variants beyond the three shipped robots (a 2-joint gantry = the point robot's URDF cut
+    # after its prismatic joints, 4 / 5 / 6-joint arms = the panda's URDF cut after joint 4 / 5 / 6)
+    "chain2": "t_chain2Mpc.yaml",
+    "chain5": "t_chain5Mpc.yaml",
+    "chain4": "t_chain4Mpc.yaml",
+    "chain6": "t_chain6Mpc.yaml",
 }
 DEFAULT_BATCH = {"cfg1": 1, "cfg2": 4096, "cfg3": 4096, "cfg4": 1024}
 
@@ -151,8 +157,8 @@ def make_scenario(name: str, B: int | None = None, seed: int = 0, **mpc_override
             todo[idx] = False
         xinit[:, 0:2] = start
         pk.setRadialConstraints(opos, orad, r_body)
-        pk.setJointLimits(POINT_LIMITS)
-        pk.setInputLimits(POINT_LIMITS_U)
+        pk.setJointLimits(POINT_LIMITS[:, :model._n])
+        pk.setInputLimits(POINT_LIMITS_U[:, :model._n])
         g3 = np.concatenate([goal, np.zeros((B, 1))], axis=1)
         pk.setGoalReaching(g3)
         extra.update(goal=g3, r_body=r_body, obst_pos=opos, obst_radius=orad)
@@ -200,9 +206,11 @@ def make_scenario(name: str, B: int | None = None, seed: int = 0, **mpc_override
             extra.update(lin_constrs=lin)
     elif robot == "panda":
         r_body = 0.14
-        q0 = np.median(PANDA_LIMITS, axis=0)[None, :] + (rng.uniform(-0.3, 0.3, size=(B, 7)) if B > 1 else 0.0)
-        q0 = np.clip(q0, PANDA_LIMITS[0] + 0.05, PANDA_LIMITS[1] - 0.05)
-        xinit[:, 0:7] = q0
+        nj = model._n   # (7 for the panda; the test configuration chain5 cuts the chain after joint 5)
+        lim, limu = PANDA_LIMITS[:, :nj], PANDA_LIMITS_U[:, :nj]
+        q0 = np.median(lim, axis=0)[None, :] + (rng.uniform(-0.3, 0.3, size=(B, 7))[:, :nj] if B > 1 else 0.0)
+        q0 = np.clip(q0, lim[0] + 0.05, lim[1] - 0.05)
+        xinit[:, 0:nj] = q0
         jit = (lambda s, sz: rng.uniform(-s, s, size=sz)) if B > 1 else (lambda s, sz: np.zeros(sz))
         goal = np.array([0.1, -0.6, 0.4]) + jit(0.15, (B, 3))
         opos = (np.array([0.5, -0.3, 0.3]) + jit(0.1, (B, 3)))[:, None, :]
@@ -225,8 +233,8 @@ def make_scenario(name: str, B: int | None = None, seed: int = 0, **mpc_override
             opos[badm, 0, :] = near[badm] + dirn[badm] * (0.1 + r_body + 0.06)
         pk.setRadialConstraints(opos, np.full((B, 1), 0.1), r_body)
         pk.setSelfCollisionAvoidanceConstraints(r_body)
-        pk.setJointLimits(PANDA_LIMITS)
-        pk.setInputLimits(PANDA_LIMITS_U)
+        pk.setJointLimits(lim)
+        pk.setInputLimits(limu)
         pk.setGoalReaching(goal)
         extra.update(goal=goal, r_body=r_body, obst_pos=opos)
     else:

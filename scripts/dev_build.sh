@@ -1,6 +1,7 @@
 #!/bin/bash
-# development aid: quick build of a subset of the kernel variants into csrc/librmpc_hip_dev.so
-#   scripts/dev_build.sh 0x4 [-DRMPC_STAMPS ...]     (bit i = variant i of variant_of(): 0 point robot, 2 panda, 5 boxer + slack ...)
+# development aid: quick one-unit build of a subset of the kernel variants into csrc/librmpc_hip_dev.so
+#   scripts/dev_build.sh 0x4 [-DRMPC_STAMPS ...]     (bit i = variant i of RMPC_VARIANTS: 0 point robot, 2 panda, 5 boxer + slack,
+#                                                      6 .. 9 chains n = 2, 4, 5, 6)
 # use with RMPC_ALLOW_STALE=1 RMPC_LIB_PATH=$PWD/robot_mpcs_amd/csrc/librmpc_hip_dev.so
 set -e
 cd "$(dirname "$0")/../robot_mpcs_amd/csrc"

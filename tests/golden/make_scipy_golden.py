@@ -4,7 +4,7 @@ N=30, cfg3 N=30 with slack, cfg4 N=20), computed from the numpy restatement of t
 only, stage-wise finite-difference Jacobians) -- nothing of rmpc_oracle.c or of the HIP kernels takes part.
 
   * 64 seeded instances per robot through SLSQP (active-set SQP);
-  * the first 8 of each again through trust-constr (trust-region interior point): a second algorithm family;
+  * the first few of each (6 / 2 / 2) again through trust-constr (trust-region interior point): a second algorithm family;
   * one warm-started closed loop per robot: 6 control steps, the plant is the numpy ERK2 map, every solve starts
     from the shifted previous plan (shiftHorizon, mpcPlanner.py:215-226);
   * a sensitivity line for the ERK2 tableau the reference's code generator uses (unverifiable here, SURVEY.md 8a
@@ -27,7 +27,11 @@ from robot_mpcs_amd.scenarios import make_scenario  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scipy_full_horizon.npz")
 CASES = [("cfg2", 64, 101), ("cfg3", 64, 102), ("cfg4", 64, 103)]
-N_TC = 8        # instances solved again with trust-constr
+# instances solved again with trust-constr and its iteration limit (a BFGS interior-point method on 270 .. 420 variables
+# with finite-difference Jacobians: 0.6 .. 3 s per iteration; it is stopped at the limit, by which it agrees with SLSQP to
+# 1e-6 in the first control)
+N_TC = {"cfg2": 6, "cfg3": 2, "cfg4": 2}
+TC_MAXITER = {"cfg2": 250, "cfg3": 150, "cfg4": 120}
 N_HEUN = 8      # boxers solved again with Heun's rule
 LOOP_STEPS = 6
 
@@ -55,7 +59,7 @@ def job(task):
     try:
         nlp = ref.StructuredNLP(sc.desc, sc.xinit[b], sc.params[b])
         if kind == "tc":
-            Z, res = nlp.solve_trust_constr(sc.x0[b])
+            Z, res = nlp.solve_trust_constr(sc.x0[b], maxiter=TC_MAXITER[name])
             out = dict(z=Z, fun=float(res.fun), status=int(res.status), nit=int(res.nit), viol=_violation(nlp, Z))
         elif kind == "loop":
             x = sc.xinit[b].copy()
@@ -84,7 +88,7 @@ def main():
     for name, B, _ in CASES:
         tasks += [("loop", name, 0)]
     for name, B, _ in reversed(CASES):            # longest jobs first
-        tasks += [("tc", name, b) for b in range(N_TC)]
+        tasks += [("tc", name, b) for b in range(N_TC[name])]
         tasks += [("slsqp", name, b) for b in range(B)]
     tasks += [("heun", "cfg3", b) for b in range(N_HEUN)]
     with Pool(workers) as pool:
@@ -97,7 +101,7 @@ def main():
                     name + "_z": np.array([x["z"] for x in r]), name + "_status": np.array([x["status"] for x in r], dtype=np.int32),
                     name + "_fun": np.array([x["fun"] for x in r]), name + "_nit": np.array([x["nit"] for x in r], dtype=np.int32),
                     name + "_viol": np.array([x["viol"] for x in r]), name + "_seed": np.array([seed])})
-        t = [results[("tc", name, b)] for b in range(N_TC)]
+        t = [results[("tc", name, b)] for b in range(N_TC[name])]
         out.update({name + "_tc_z": np.array([x["z"] for x in t]), name + "_tc_fun": np.array([x["fun"] for x in t]),
                     name + "_tc_viol": np.array([x["viol"] for x in t]), name + "_tc_status": np.array([x["status"] for x in t], dtype=np.int32)})
         lp = results[("loop", name, 0)]

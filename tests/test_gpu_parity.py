@@ -52,6 +52,9 @@ def _check_plan(gpu, cpu, nxs, tol_stat=1e-6):
     # VelLimitConstraints rows and a non-zero ConstraintAvoidance weight on every module (single-variable rows
     # as "first row of a module", Linear rows, self-collision rows)
     ("wc_point", 96, 31), ("wc_boxer", 96, 32), ("wc_boxer_slack", 96, 33), ("wc_panda", 40, 34),
+    # kernel variants beyond the three shipped robots (mpcBase.py:52-55: n = fk.n() of any URDF chain): a 2-joint
+    # gantry (fused kernel) and 4 / 5 / 6-joint arms (pass kernels; n = 5, 6 with the cost-to-go update on the matrix cores)
+    ("chain2", 96, 41), ("chain4", 48, 42), ("chain5", 48, 43), ("chain6", 48, 44),
 ])
 def test_solve_matches_oracle(rt, name, B, seed):
     sc = rt["make_scenario"](name, B=B, seed=seed)
@@ -69,6 +72,7 @@ def test_solve_matches_oracle(rt, name, B, seed):
     # its recursion the stage matrices; 420 B of scratch per lane), a weighted arm, and horizons beyond the fused
     # kernel's 32 stages (point robot and boxer through k_sweep / k_riccati / k_step, with survivor migration)
     ("cfg4", 256, {}), ("wc_panda", 64, {}), ("cfg2", 1536, {"time_horizon": 40}), ("cfg3", 192, {"time_horizon": 36}),
+    ("chain2", 64, {}), ("chain5", 64, {}),
 ])
 def test_solve_does_not_depend_on_stale_lds(rt, name, B, kw):
     """Every word a kernel reads from LDS, scratch or the handle's workspace must have been written by the same solve:
@@ -520,7 +524,7 @@ def test_is_fused_tells_which_solves_need_no_host_look(rt, monkeypatch):
     """rmpc_is_fused: the point robot and the diff-drive base (N <= 32) solve in one launch, the arm and long horizons
     through the pass kernels; RMPC_NO_FUSED=1 (read at rmpc_create) sends everything through the pass kernels."""
     monkeypatch.delenv("RMPC_NO_FUSED", raising=False)
-    want = {"cfg2": True, "cfg3": True, "cfg4": False}
+    want = {"cfg2": True, "cfg3": True, "cfg4": False, "chain2": True, "chain5": False}
     for name, fused in want.items():
         sc = rt["make_scenario"](name, B=4, seed=1)
         s = rt["Solver"](sc.desc, max_batch=4)
