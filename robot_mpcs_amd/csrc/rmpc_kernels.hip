@@ -1613,9 +1613,18 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     const int lr = lane < NX ? lane : 0;
     // gains: lane c <= NX solves for column c of K (c < NX) or for kff (c == NX); sq follows sQ in the work area
     const int lc = lane <= NX ? lane : 0;
+    // Every store of a phase is unconditional: a lane without an entry writes to a word of its own in the staging
+    // area of the generic path (srec, unused here) instead of skipping the store -- a predicated store makes the
+    // compiler cut the phase into exec-masked blocks with their own waits (15 of them per stage before).
+    ldouble *const dummy = srec + lane;
+    ldouble *qdst[EPL];
+#pragma unroll
+    for (int u = 0; u < EPL; u++) qdst[u] = (lane + LPI * u < NV * NV) ? sQ + lane + LPI * u : dummy;
+    ldouble *const sqdst = lane < NV ? sq + lane : dummy;
     // cost-to-go entries of this lane (see the generic path): P(i, j) for e < NX*NX, then p(i)
     constexpr int PPL2 = (NX * NX + NX + LPI - 1) / LPI;
-    int pa0[PPL2], pc0[PPL2], pqa[PPL2], pqc[PPL2], pka[PPL2], pkc[PPL2], pks[PPL2];
+    int pa0[PPL2], pc0[PPL2], pqa[PPL2], pqc[PPL2], pka[PPL2], pkc[PPL2], pks[PPL2], pslot[PPL2];
+    ldouble *pdst1[PPL2];
     bool pisP[PPL2], pok[PPL2];
 #pragma unroll
     for (int u = 0; u < PPL2; u++) {
@@ -1633,6 +1642,9 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       pka[u] = isP ? j : OFF_KFF;                    // K[l][j] = slot[l*NX + j]  |  kff[l] = slot[OFF_KFF + l]
       pkc[u] = isP ? i : OFF_KFF;
       pks[u] = isP ? NX : 1;                         // stride over l
+      // where the entry goes: work area (sP / sp) and the stage's image (upper triangle of P packed, p); -1: nowhere
+      pdst1[u] = !pok[u] ? dummy : (isP ? sP + ec : sp + (ec - NX * NX));
+      pslot[u] = !pok[u] ? -1 : (isP ? (i <= j ? OFF_PT + tri(i, j) : -1) : OFF_P + (ec - NX * NX));
     }
     for (int k = N - 1; k >= 0; k--) {
       ldouble *const slot = slots + (size_t)k * GS;   // record of stage k; becomes its image [K | kff | Pt | p | rc]
@@ -1648,20 +1660,21 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       for (int l = 0; l < NX; l++) { rcl[l] = slot[C::R_RC + l]; pr1[l] = sP[iq * NX + l]; pr2[l] = sP[(NQ + iq) * NX + l]; }
       double pc1 = sp[iq], pc2 = sp[NQ + iq];
       const double q0v = slot[C::R_Q0 + lv], q1v = slot[C::R_Q1 + lv], rcme = slot[C::R_RC + lr];
+      __builtin_amdgcn_sched_barrier(0);   // (every read of the phase is issued before the first use: one counted wait instead of a wait per use)
 #pragma unroll
       for (int u = 0; u < EPL; u++) {
         double v = r0[u] - cwt * r1[u];
         v += l1[u] * (c1[u] * a11[u] + c2[u] * a12[u]) + l2[u] * (c1[u] * a21[u] + c2[u] * a22[u]);
-        if (qok[u]) sQ[lane + LPI * u] = v;
+        *qdst[u] = v;
       }
 #pragma unroll
       for (int l = 0; l < NX; l++) { pc1 += pr1[l] * rcl[l]; pc2 += pr2[l] * rcl[l]; }
       {
         double v = q0v - mu * q1v;
         v += l1q * pc1 + l2q * pc2;
-        if (lane < NV) sq[lane] = v;
+        *sqdst = v;
       }
-      if (lane < NX) slot[OFF_RC + lane] = rcme;   // (behind the record: [OFF_RC, OFF_RC + NX) is step space, dead now)
+      *(lane < NX ? slot + OFF_RC + lane : dummy) = rcme;   // (behind the record: [OFF_RC, OFF_RC + NX) is step space, dead now)
       WSYNC();
       // ---- phase B: Cholesky of Qww (every lane, registers) and the gains (one column per lane) -------------
       double qw[NW][NW], colv[NW];
@@ -1671,6 +1684,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
         for (int i = j; i < NW; i++) qw[i][j] = sQ[(NX + i) * NV + NX + j];
 #pragma unroll
       for (int i = 0; i < NW; i++) colv[i] = sQ[lc < NX ? (NX + i) * NV + lc : NV * NV + NX + i];
+      __builtin_amdgcn_sched_barrier(0);   // (every read of the phase is issued before the first use: one counted wait instead of a wait per use)
       double L[NW][NW], invd[NW];
 #pragma unroll
       for (int j = 0; j < NW; j++) {
@@ -1696,9 +1710,11 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
 #pragma unroll
         for (int i = 0; i < NW; i++) col[i] = -colv[i];
         chol_solve<NW>(L, invd, col);
-        if (lane <= NX) {
+        {
+          ldouble *const kdst = lane <= NX ? slot + (lane < NX ? lane : OFF_KFF) : dummy;
+          const int kstr = lane < NX ? NX : (lane == NX ? 1 : 0);
 #pragma unroll
-          for (int i = 0; i < NW; i++) slot[lane < NX ? i * NX + lane : OFF_KFF + i] = col[i];
+          for (int i = 0; i < NW; i++) kdst[i * kstr] = col[i];
         }
       }
       WSYNC();
@@ -1713,6 +1729,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
           ka[u][l] = slot[pka[u] + l * pks[u]]; kc[u][l] = slot[pkc[u] + l * pks[u]];
         }
       }
+      __builtin_amdgcn_sched_barrier(0);   // (every read of the phase is issued before the first use: one counted wait instead of a wait per use)
 #pragma unroll
       for (int u = 0; u < PPL2; u++) {
         double a = pa[u], c = pcc[u];
@@ -1722,17 +1739,8 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
           c += qc[u][l] * kc[u][l];
         }
         const double pn = 0.5 * (a + c);
-        const int e = lane + LPI * u;
-        if (pok[u]) {
-          if (pisP[u]) {
-            sP[e] = pn;
-            const int i = e / NX, j = e - i * NX;
-            if (i <= j) slot[OFF_PT + tri(i, j)] = pn;
-          } else {
-            sp[e - NX * NX] = pn;
-            slot[OFF_P + (e - NX * NX)] = pn;
-          }
-        }
+        *pdst1[u] = pn;                                      // work area: sP / sp, read by the next stage's phase A
+        *(pslot[u] >= 0 ? slot + pslot[u] : dummy) = pn;     // image of the stage: packed triangle / p
       }
       WSYNC();   // (sP / sp of this stage are read by the next stage's phase A)
     }
@@ -2260,6 +2268,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       for (int j = 0; j < NX; j++) { dx[j] = dxc[j]; kr[j] = im[iw * NX + j]; pr[j] = im[OFF_PT + tro[j]]; }
       const double kf = im[OFF_KFF + iw], pv = im[OFF_P + in], rcv = im[OFF_RC + lx];
       const double dxme = dxc[lx], dxv = dxc[isq ? NQ + lx : lx], dxo = dxc[in];
+      __builtin_amdgcn_sched_barrier(0);   // (every read of the phase is issued before the first use: one counted wait instead of a wait per use)
       double dw = kf, nup = pv;
 #pragma unroll
       for (int j = 0; j < NX; j++) { dw += kr[j] * dx[j]; nup += pr[j] * dx[j]; }
@@ -2940,10 +2949,11 @@ struct FusedWs {
 // recursion's stage loop to make room for the sweep's straight-line code (measured with the generated views:
 // recursion 83 k -> 125 k cycles per pass).  As callees every phase gets the whole register file to itself and the
 // few words that live across a call are saved once around it.
+#define RMPC_ONE_WAVE   // (occupancy attributes are kernel-only in clang: the phase functions inherit k_fused's, see there)
 #ifdef RMPC_NOINLINE_OFF
 #define RMPC_PHASE __forceinline__
 #else
-#define RMPC_PHASE __noinline__
+#define RMPC_PHASE __noinline__ RMPC_ONE_WAVE
 #endif
 template <class C>
 __device__ RMPC_PHASE bool fused_recursion_lds(const int N, const double dt, const double mu, const bool usec, const int lane,
@@ -2989,7 +2999,7 @@ __device__ __forceinline__ FusedPtrs fused_ptrs(const FusedWs &F, size_t b) {
 // the sweep stores by design (round 2, L2 counters: 60 % of the fabric traffic of a launch were writes).
 struct StepRes { double ap, ad, gp; };
 template <class C, class V, int FIRSTC, bool REC_LDS>
-__device__ __noinline__ Partials fused_sweep_call(const FusedWs *Fp, const int N, const double dt, const int use_curv,
+__device__ __noinline__ RMPC_ONE_WAVE Partials fused_sweep_call(const FusedWs *Fp, const int N, const double dt, const int use_curv,
                                                   const size_t b, const int cur, const int k, ldouble *const slots,
                                                   const bool nostep, const double alpha, const double adual, const double mu,
                                                   const int warm) {
@@ -3022,7 +3032,7 @@ __device__ __noinline__ Partials fused_sweep_call(const FusedWs *Fp, const int N
   return q;
 }
 template <class C, class V, bool REC_LDS>
-__device__ __noinline__ StepRes fused_step_call(const FusedWs *Fp, const size_t b, const int cur, const int k,
+__device__ __noinline__ RMPC_ONE_WAVE StepRes fused_step_call(const FusedWs *Fp, const size_t b, const int cur, const int k,
                                                 ldouble *const slots, const double mu) {
   using RP = typename std::conditional<REC_LDS, ldouble, gdouble>::type;
   constexpr int GS = FusedSlots<C>::GS, DZ_OFF = FusedSlots<C>::DZ_OFF;
@@ -3048,7 +3058,7 @@ __device__ __noinline__ StepRes fused_step_call(const FusedWs *Fp, const size_t 
 // and a pass is two calls: this one and the recursion (1.90-1.94 -> 1.97-2.03 M solves/s, same results).
 struct SweepStepRes { Partials q; double amin_p, amin_d, gphi; };
 template <class C, class V, int FIRSTC>
-__device__ __noinline__ SweepStepRes fused_sweep_step_call(const FusedWs *Fp, const int N, const double dt, const int use_curv,
+__device__ __noinline__ RMPC_ONE_WAVE SweepStepRes fused_sweep_step_call(const FusedWs *Fp, const int N, const double dt, const int use_curv,
                                                            const size_t b, const int cur, const int k, ldouble *const slots,
                                                            const bool live, const bool nostep, const bool fresh, const int ls,
                                                            const double amin_p_in, const double amin_d_in, const double gphi_in,
@@ -3093,8 +3103,12 @@ __device__ __noinline__ SweepStepRes fused_sweep_step_call(const FusedWs *Fp, co
   return r;
 }
 
+// (amdgpu_waves_per_eu(1, 1): __launch_bounds__' second argument only sets the MINIMUM of waves per SIMD; with the
+//  maximum open the instruction scheduler still plans the phase functions -- which inherit the attribute -- for as
+//  many waves as it can reach and keeps their register pressure down by serialising the LDS reads of a phase:
+//  load, wait, use, load, wait, use.  One wave per SIMD is what the kernel gets anyway: 38 KB of LDS.)
 template <class C, bool REC_LDS, class V>
-__global__ __launch_bounds__(64, 1) void k_fused(const DevModel M, const DevTables *__restrict__ Tp, const FusedWs F, const int B,
+__global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_fused(const DevModel M, const DevTables *__restrict__ Tp, const FusedWs F, const int B,
                                               const double *__restrict__ xinit, const double *__restrict__ x0,
                                               const double *__restrict__ params, double *__restrict__ zout,
                                               int *__restrict__ exitflag, int *__restrict__ iters_out,

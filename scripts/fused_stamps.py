@@ -16,11 +16,14 @@ sc = make_scenario(cfg, B=B, seed=1000)
 s = Solver(sc.desc, max_batch=B)
 s.solve(sc.xinit, sc.x0, sc.params)
 r = s.solve(sc.xinit, sc.x0, sc.params)
-nb = (B + 1) // 2
+# the launch is a queue drained by at most one wavefront per SIMD (4 x compute units; RMPC_FUSED_GRID overrides)
+nb = min((B + 1) // 2, int(os.environ.get("RMPC_FUSED_GRID", "1024")))
 both = s.fused_stamps(2 * nb).astype(float)
 st, sec = both[:nb], both[nb:]
 tot = st[:, 4]
-print(f"{cfg} B={B}: blocks {len(st)}, passes mean {st[:, 5].mean():.1f} max {st[:, 5].max():.0f}")
+print(f"{cfg} B={B}: wavefronts {len(st)}, passes per wavefront mean {st[:, 5].mean():.1f} max {st[:, 5].max():.0f}, "
+      f"instance passes per wavefront pass {st[:, 7].sum() / st[:, 5].sum():.2f} (2 = both halves busy), "
+      f"passes per instance mean {st[:, 7].sum() / B:.1f}")
 for i, name in enumerate(["sweep", "decide", "riccati", "step"]):
     print(f"  {name:8s} {st[:, i].sum() / tot.sum() * 100:5.1f} %   cycles per pass {st[:, i].sum() / st[:, 5].sum():9.0f}")
 if sec[:, :4].sum() > 0:
