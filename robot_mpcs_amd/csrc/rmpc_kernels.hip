@@ -1830,8 +1830,50 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
 #pragma unroll
       for (int u = 0; u < 2; u++) abn[u] = r[C::R_A5 + (lane + LPI * u < 35 ? lane + LPI * u : 0)];
     };
-    // cost-to-go entries of this lane (as in the generic path)
+    // cost-to-go entries of this lane (as in the generic path): offsets of what an entry is made of, relative to the
+    // work area (sQ, sq, sK, skf all live in it), and where it goes
     constexpr int PPL2 = (NX * NX + NX + LPI - 1) / LPI;
+    static_assert(KPW % 8 != 0, "the gain record needs a spare word behind the image (stores of idle lanes)");
+    // Every store of a phase is unconditional (a lane without an entry writes to a word of its own in the unused
+    // staging area, or to the spare word behind the stage's gain record) and every read of a phase is issued before
+    // its first use: a stage is straight-line code with one counted wait per phase instead of two dozen exec-masked
+    // blocks that each wait for their own reads (as for the chain's path above).
+    ldouble *const dummy = srec + lane;
+    int da0[PPL2], dc0[PPL2], dqa[PPL2], dqc[PPL2], dka[PPL2], dkc[PPL2], dks[PPL2], dkp[PPL2];
+    ldouble *dd1[PPL2], *dd2[PPL2];
+#pragma unroll
+    for (int u = 0; u < PPL2; u++) {
+      const int e = lane + LPI * u;
+      const bool okp = e < NX * NX + NX;
+      const int ec = okp ? e : 0;
+      const bool isP = ec < NX * NX;
+      const int i = isP ? ec / NX : ec - NX * NX, j = isP ? ec - i * NX : 0;
+      da0[u] = isP ? (int)(sQ - img) + i * NV + j : (int)(sq - img) + i;
+      dc0[u] = isP ? (int)(sQ - img) + j * NV + i : (int)(sq - img) + i;
+      dqa[u] = (int)(sQ - img) + i * NV + NX;
+      dqc[u] = (int)(sQ - img) + (isP ? j : i) * NV + NX;
+      dka[u] = isP ? (int)(sK - img) + j : (int)(skf - img);
+      dkc[u] = isP ? (int)(sK - img) + i : (int)(skf - img);
+      dks[u] = isP ? NX : 1;
+      dd1[u] = !okp ? dummy : (isP ? sP + ec : sp + (ec - NX * NX));
+      dd2[u] = (okp && isP && i <= j) ? sPt + tri(i, j) : dummy;
+      dkp[u] = !okp ? KPW : (isP ? (i <= j ? OFF_PT + tri(i, j) : KPW) : OFF_P + (ec - NX * NX));
+    }
+    ldouble *tdst[TA];
+#pragma unroll
+    for (int u = 0; u < TA; u++) tdst[u] = tok[u] ? sT7 + tst[u] : dummy;
+    ldouble *qdst[EPL];
+#pragma unroll
+    for (int u = 0; u < EPL; u++) qdst[u] = bok[u] ? sQ + lane + LPI * u : dummy;
+    ldouble *const pcdst = lane < NX ? sPc + lane : dummy, *const sqdst = lane < NV ? sq + lane : dummy;
+    ldouble *const srcdst = lane < NX ? src + lane : dummy;
+    ldouble *abdst[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) abdst[u] = lane + LPI * u < 35 ? sAB + lane + LPI * u : dummy;
+    const int lc = lane <= NX ? lane : 0;                           // gain column of this lane (NX: kff)
+    ldouble *const kdst = lane <= NX ? img + (lane < NX ? lane : OFF_KFF) : dummy;
+    const int kgo = lane <= NX ? (lane < NX ? lane : OFF_KFF) : KPW, kstr = lane < NX ? NX : (lane == NX ? 1 : 0);
+    const int rco = lane < NX ? OFF_RC + lane : KPW;
     if (lane == 0) sZ[0] = 0.0;
     fetch_dd(N - 1);
     for (int k = N - 1; k >= 0; k--) {
@@ -1847,58 +1889,81 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       WSYNC();   // P, p of stage k+1 and [A5 | B5], rc of this stage are in LDS
       if (rec_cost) {
         // ---- phase A: T = P [A|B] (computed columns), Pc = P rc + p ------------------------------------------
+        double ta[TA][NR], tb[TA][NR], pr[NX], rcl[NX];
+#pragma unroll
+        for (int u = 0; u < TA; u++)
+#pragma unroll
+          for (int r = 0; r < NR; r++) { ta[u][r] = sP[tpo[u] + Rl(r)]; tb[u][r] = sAB[tco[u] + r * tcs[u]]; }
+#pragma unroll
+        for (int l = 0; l < NX; l++) { pr[l] = sP[lr * NX + l]; rcl[l] = src[l]; }
+        double pcv = sp[lr];
+        __builtin_amdgcn_sched_barrier(0);
         double tv[TA];
 #pragma unroll
         for (int u = 0; u < TA; u++) {
           double sacc = 0.0;
 #pragma unroll
-          for (int r = 0; r < NR; r++) sacc += sP[tpo[u] + Rl(r)] * sAB[tco[u] + r * tcs[u]];
+          for (int r = 0; r < NR; r++) sacc += ta[u][r] * tb[u][r];
           tv[u] = sacc;
         }
-        double pcv = 0.0;
-        if (lane < NX) {
-          pcv = sp[lane];
 #pragma unroll
-          for (int l = 0; l < NX; l++) pcv += sP[lane * NX + l] * src[l];
-        }
+        for (int l = 0; l < NX; l++) pcv += pr[l] * rcl[l];
 #pragma unroll
-        for (int u = 0; u < TA; u++)
-          if (tok[u]) sT7[tst[u]] = tv[u];
-        if (lane < NX) sPc[lane] = pcv;
+        for (int u = 0; u < TA; u++) *tdst[u] = tv[u];
+        *pcdst = pcv;
         WSYNC();
       }
       // ---- phase B: Q = record + [A|B]^T T, q = q0 - mu q1 + [A|B]^T Pc ----------------------------------------
       {
         double qv[EPL];
-#pragma unroll
-        for (int u = 0; u < EPL; u++) {
-          double v = rqc[u];   // (the diff-drive model carries no curvature block: cwt * 0)
-          if (rec_cost) {
-#pragma unroll
-            for (int r = 0; r < NR; r++) v += img[bco[u] + r * bcs[u]] * img[bto[u] + Rl(r) * bts[u]];
-            v += bI[u] ? img[bio[u]] : 0.0;
-          }
-          qv[u] = v;
-        }
         double gq = q0c - mu * q1c;
         if (rec_cost) {
+          double ba[EPL][NR], bb[EPL][NR], bi[EPL], ga[NR], gb[NR];
 #pragma unroll
-          for (int r = 0; r < NR; r++) gq += img[qco + r * qcs] * sPc[Rl(r)];
-          gq += qI ? sPc[lq < NX ? lq : 0] : 0.0;
+          for (int u = 0; u < EPL; u++) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) { ba[u][r] = img[bco[u] + r * bcs[u]]; bb[u][r] = img[bto[u] + Rl(r) * bts[u]]; }
+            bi[u] = img[bio[u]];
+          }
+#pragma unroll
+          for (int r = 0; r < NR; r++) { ga[r] = img[qco + r * qcs]; gb[r] = sPc[Rl(r)]; }
+          const double gi = sPc[lq < NX ? lq : 0];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < EPL; u++) {
+            double v = rqc[u];   // (the diff-drive model carries no curvature block: cwt * 0)
+#pragma unroll
+            for (int r = 0; r < NR; r++) v += ba[u][r] * bb[u][r];
+            v += bI[u] ? bi[u] : 0.0;
+            qv[u] = v;
+          }
+#pragma unroll
+          for (int r = 0; r < NR; r++) gq += ga[r] * gb[r];
+          gq += qI ? gi : 0.0;
+        } else {
+#pragma unroll
+          for (int u = 0; u < EPL; u++) qv[u] = rqc[u];
         }
 #pragma unroll
-        for (int u = 0; u < EPL; u++)
-          if (bok[u]) sQ[lane + LPI * u] = qv[u];
-        if (lane < NV) sq[lane] = gq;
-        if (lane < NX) kpk[OFF_RC + lane] = rcc;   // the stage's defect: part of its gain image
+        for (int u = 0; u < EPL; u++) *qdst[u] = qv[u];
+        *sqdst = gq;
+        kpk[rco] = rcc;   // the stage's defect: part of its gain image
       }
       WSYNC();
       // ---- phase C: Cholesky of Qww (every lane, registers) and the gains (one column per lane) ----------------
       {
+        double qw[NW][NW], colv[NW];
+#pragma unroll
+        for (int j = 0; j < NW; j++)
+#pragma unroll
+          for (int i = j; i < NW; i++) qw[i][j] = sQ[(NX + i) * NV + NX + j];
+#pragma unroll
+        for (int i = 0; i < NW; i++) colv[i] = lc < NX ? sQ[(NX + i) * NV + lc] : sq[NX + i];
+        __builtin_amdgcn_sched_barrier(0);
         double L[NW][NW], invd[NW];
 #pragma unroll
         for (int j = 0; j < NW; j++) {
-          double dg = sQ[(NX + j) * NV + NX + j];
+          double dg = qw[j][j];
 #pragma unroll
           for (int l = 0; l < j; l++) dg -= L[j][l] * L[j][l];
           if (!(dg > 0.0)) chol_ok = false;
@@ -1909,69 +1974,54 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
           invd[j] = inv;
 #pragma unroll
           for (int i = j + 1; i < NW; i++) {
-            double sacc = sQ[(NX + i) * NV + NX + j];
+            double sacc = qw[i][j];
 #pragma unroll
             for (int l = 0; l < j; l++) sacc -= L[i][l] * L[j][l];
             L[i][j] = sacc * inv;
           }
         }
-        if (lane <= NX) {
-          double col[NW];
+        double col[NW];
 #pragma unroll
-          for (int i = 0; i < NW; i++) col[i] = (lane < NX) ? -sQ[(NX + i) * NV + lane] : -sq[NX + i];
-          chol_solve<NW>(L, invd, col);
+        for (int i = 0; i < NW; i++) col[i] = -colv[i];
+        chol_solve<NW>(L, invd, col);
 #pragma unroll
-          for (int i = 0; i < NW; i++) {
-            const int o = lane < NX ? i * NX + lane : OFF_KFF + i;
-            img[o] = col[i];
-            kpk[o] = col[i];
-          }
+        for (int i = 0; i < NW; i++) {
+          kdst[i * kstr] = col[i];
+          kpk[kgo + i * kstr] = col[i];
         }
       }
       WSYNC();
       // ---- phase D: cost-to-go P = sym(Qxx + Qxw K), p = qx + Qxw kff; [A5 | B5], rc of the next stage to LDS -----
       {
-        double pn[PPL2];
+        double a0[PPL2], c0[PPL2], qa[PPL2][NW], qc[PPL2][NW], ka[PPL2][NW], kc[PPL2][NW];
 #pragma unroll
         for (int u = 0; u < PPL2; u++) {
-          const int e = lane + LPI * u;
-          pn[u] = 0.0;
-          if (e < NX * NX + NX) {
-            const bool isP = e < NX * NX;
-            const int i = isP ? e / NX : e - NX * NX, j = isP ? e - i * NX : 0;
-            const ldouble *const a0 = isP ? sQ + i * NV + j : sq + i;
-            const ldouble *const c0 = isP ? sQ + j * NV + i : sq + i;
-            const ldouble *const cq = isP ? sQ + j * NV + NX : sQ + i * NV + NX;
-            double a = *a0, c = *c0;
+          a0[u] = img[da0[u]]; c0[u] = img[dc0[u]];
 #pragma unroll
-            for (int l = 0; l < NW; l++) {
-              a += sQ[i * NV + NX + l] * (isP ? sK[l * NX + j] : skf[l]);
-              c += cq[l] * (isP ? sK[l * NX + i] : skf[l]);
-            }
-            pn[u] = 0.5 * (a + c);
+          for (int l = 0; l < NW; l++) {
+            qa[u][l] = img[dqa[u] + l]; qc[u][l] = img[dqc[u] + l];
+            ka[u][l] = img[dka[u] + l * dks[u]]; kc[u][l] = img[dkc[u] + l * dks[u]];
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < PPL2; u++) {
-          const int e = lane + LPI * u;
-          if (e < NX * NX) {
-            sP[e] = pn[u];
-            const int i = e / NX, j = e - i * NX;
-            if (i <= j) { sPt[tri(i, j)] = pn[u]; kpk[OFF_PT + tri(i, j)] = pn[u]; }
-          } else if (e < NX * NX + NX) {
-            sp[e - NX * NX] = pn[u];
-            kpk[OFF_P + (e - NX * NX)] = pn[u];
-          }
-        }
-        if (k > 0) {
-          // (what fetch_dd(k - 1) brought: nobody reads sAB / src again before the ordering point at the loop top)
+          double a = a0[u], c = c0[u];
 #pragma unroll
-          for (int u = 0; u < 2; u++)
-            if (lane + LPI * u < 35) sAB[lane + LPI * u] = abn[u];
-          if (lane < NX) src[lane] = rcn;
-        } else if (lane < NX) {
-          src[lane] = rcc;   // (single-stage horizon: the forward pass reads the defect of stage 0 from the image)
+          for (int l = 0; l < NW; l++) {
+            a += qa[u][l] * ka[u][l];
+            c += qc[u][l] * kc[u][l];
+          }
+          const double pn = 0.5 * (a + c);
+          *dd1[u] = pn;
+          *dd2[u] = pn;
+          kpk[dkp[u]] = pn;
         }
+        // (what fetch_dd(k - 1) brought: nobody reads sAB / src again before the ordering point at the loop top;
+        //  single-stage horizon: the forward pass reads the defect of stage 0 from the image)
+#pragma unroll
+        for (int u = 0; u < 2; u++) *(k > 0 ? abdst[u] : dummy) = abn[u];
+        *srcdst = k > 0 ? rcn : rcc;
       }
     }
   }
@@ -2324,50 +2374,63 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     const bool xI = rid(lx) < 0;
     const int ao = xI ? 35 : rid(lx) * NR, as = xI ? 0 : 1;   // row of A5 (offsets in sAB; 35 = the zero word)
     const int bo = xI ? 35 : 25 + rid(lx) * 2, bs = xI ? 0 : 1;
+    // (unconditional stores and batched reads as in the backward pass)
+    ldouble *const fdummy = srec + lane;
+    ldouble *fdst[KPL], *fab[2];
+#pragma unroll
+    for (int u = 0; u < KPL; u++) fdst[u] = lane + LPI * u < KPW ? img + lane + LPI * u : fdummy;
+#pragma unroll
+    for (int u = 0; u < 2; u++) fab[u] = lane + LPI * u < 35 ? sAB + lane + LPI * u : fdummy;
+    // (the two global stores of the step stay predicated: there is no spare word in the step arrays)
     for (int k = 0; k < N; k++) {
       const ldouble *const dxc = (k & 1) ? dx1 : dx0;
       ldouble *const dxn = (k & 1) ? dx0 : dx1;
-      if (k > 0) {
-        // image and [A5 | B5] of this stage (what the previous iteration requested)
+      // image and [A5 | B5] of this stage (what the previous iteration requested; stage 0's are in place)
 #pragma unroll
-        for (int u = 0; u < KPL; u++) {
-          const int e = lane + LPI * u;
-          if (e < KPW) img[e] = fv[u];
-        }
+      for (int u = 0; u < KPL; u++) *(k > 0 ? fdst[u] : fdummy) = fv[u];
 #pragma unroll
-        for (int u = 0; u < 2; u++)
-          if (lane + LPI * u < 35) sAB[lane + LPI * u] = abf[u];
-      }
+      for (int u = 0; u < 2; u++) *(k > 0 ? fab[u] : fdummy) = abf[u];
       if (k + 1 < N) fetch_f(k + 1);
       WSYNC();
-      double dx[NX];
+      double dx[NX], rw[NX], ku[2][NX], ar[NR], br[2];
 #pragma unroll
-      for (int j = 0; j < NX; j++) dx[j] = dxc[j];
+      for (int j = 0; j < NX; j++) { dx[j] = dxc[j]; rw[j] = img[ro[j]]; }
+      const double own0 = img[oo];
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int j = 0; j < NX; j++) ku[c][j] = img[(NS + c) * NX + j];
+      const double kf0 = img[OFF_KFF + NS], kf1 = img[OFF_KFF + NS + 1];
+#pragma unroll
+      for (int r = 0; r < NR; r++) ar[r] = sAB[ao + r * as];
+#pragma unroll
+      for (int c = 0; c < 2; c++) br[c] = sAB[bo + c * bs];
+      const double rcv = img[OFF_RC + lx];
+      const double dxo = dxc[in], dxme = dxc[lx];
+      __builtin_amdgcn_sched_barrier(0);
       // own entry of the step / costate
-      double sown = img[oo];
+      double sown = own0;
 #pragma unroll
-      for (int j = 0; j < NX; j++) sown += img[ro[j]] * dx[j];
+      for (int j = 0; j < NX; j++) sown += rw[j] * dx[j];
       // the two input steps (every lane: the dx+ lanes need them)
       double du[2];
 #pragma unroll
       for (int c = 0; c < 2; c++) {
-        double sacc = img[OFF_KFF + NS + c];
+        double sacc = c == 0 ? kf0 : kf1;
 #pragma unroll
-        for (int j = 0; j < NX; j++) sacc += img[(NS + c) * NX + j] * dx[j];
+        for (int j = 0; j < NX; j++) sacc += ku[c][j] * dx[j];
         du[c] = sacc;
       }
-      const double rcv = img[OFF_RC + lx];
-      const double dxo = dxc[in], dxme = dxc[lx];
       if (lane < NW + NX) so.dz[(size_t)(isw ? NX + lane : in) * so.SS + (size_t)k * so.KS] = isw ? sown : dxo;
       if (isn && k >= 1) so.nunew[(size_t)in * so.SS + (size_t)k * so.KS] = sown;
-      if (k < N - 1 && lane < NX) {
+      {
         double sx = rcv;
 #pragma unroll
-        for (int r = 0; r < NR; r++) sx += sAB[ao + r * as] * dx[Rl(r)];
+        for (int r = 0; r < NR; r++) sx += ar[r] * dx[Rl(r)];
         sx += xI ? dxme : 0.0;
 #pragma unroll
-        for (int c = 0; c < 2; c++) sx += sAB[bo + c * bs] * du[c];
-        dxn[lane] = sx;
+        for (int c = 0; c < 2; c++) sx += br[c] * du[c];
+        *((k < N - 1 && lane < NX) ? dxn + lane : fdummy) = sx;
       }
     }
     return true;
