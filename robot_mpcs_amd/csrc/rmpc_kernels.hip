@@ -1833,7 +1833,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     // cost-to-go entries of this lane (as in the generic path): offsets of what an entry is made of, relative to the
     // work area (sQ, sq, sK, skf all live in it), and where it goes
     constexpr int PPL2 = (NX * NX + NX + LPI - 1) / LPI;
-    static_assert(KPW % 8 != 0, "the gain record needs a spare word behind the image (stores of idle lanes)");
+    // (the gain record always has a spare word behind the image: kps = (KPW + 8) / 8 * 8)
     // Every store of a phase is unconditional (a lane without an entry writes to a word of its own in the unused
     // staging area, or to the spare word behind the stage's gain record) and every read of a phase is issued before
     // its first use: a stage is straight-line code with one counted wait per phase instead of two dozen exec-masked
@@ -2025,6 +2025,44 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       }
     }
   }
+  // ---- generic path (pass kernels; fused kernel of models without a path of their own): per-lane constants ----------
+  // idle lanes store to a word of the unused T area (several lanes may share one: the value is never read)
+  ldouble *const gdummy = sT + lane % (NX * NV);
+  ldouble *gsrdst[RPL];
+#pragma unroll
+  for (int u = 0; u < RPL; u++) gsrdst[u] = lane + LPI * u < C::RS ? srec + lane + LPI * u : gdummy;
+  int go11[EPL];
+  double gl1[EPL], gl2[EPL], gc1[EPL], gc2[EPL];
+  bool gon[EPL];
+  ldouble *gqdst[EPL];
+#pragma unroll
+  for (int u = 0; u < EPL; u++) {
+    const int e = lane + LPI * u;
+    const bool ok = e < NV * NV;
+    const int ec = ok ? e : 0;
+    const int i = ec / NV, j = ec - i * NV;
+    // row / column kind: 0 = q, 1 = v, 2 = u, 3 = slack (no contribution)
+    const int ki = i < NQ ? 0 : (i < NX ? 1 : (i >= NX + NS ? 2 : 3));
+    const int kj = j < NQ ? 0 : (j < NX ? 1 : (j >= NX + NS ? 2 : 3));
+    gon[u] = ok && ki != 3 && kj != 3;
+    const int ii = !gon[u] ? 0 : (ki == 0 ? i : (ki == 1 ? i - NQ : i - NX - NS));
+    const int jj = !gon[u] ? 0 : (kj == 0 ? j : (kj == 1 ? j - NQ : j - NX - NS));
+    go11[u] = ii * NX + jj;
+    // left factor: row kind picks the combination of the two block rows -- q: (1, 0); v: (h, 1); u: (h2, h)
+    gl1[u] = ki == 0 ? 1.0 : (ki == 1 ? h : h2); gl2[u] = ki == 0 ? 0.0 : (ki == 1 ? 1.0 : h);
+    gc1[u] = kj == 0 ? 1.0 : (kj == 1 ? h : h2); gc2[u] = kj == 0 ? 0.0 : (kj == 1 ? 1.0 : h);
+    gqdst[u] = ok ? sQ + e : gdummy;
+  }
+  const int glr = lane < NX ? lane : 0, glv = lane < NV ? lane : 0;
+  ldouble *const gsrc = lane < NX ? src + lane : gdummy, *const gpcdst = lane < NX ? sPc + lane : gdummy;
+  ldouble *const gsqdst = lane < NV ? sq + lane : gdummy;
+  const int gkq = glv < NQ ? 0 : (glv < NX ? 1 : (glv >= NX + NS ? 2 : 3));
+  const bool gqon = lane < NV && gkq != 3;
+  const int giq = !gqon ? 0 : (gkq == 0 ? glv : (gkq == 1 ? glv - NQ : glv - NX - NS));
+  const double gl1q = gkq == 0 ? 1.0 : (gkq == 1 ? h : h2), gl2q = gkq == 0 ? 0.0 : (gkq == 1 ? 1.0 : h);
+  const int glc = lane <= NX ? lane : 0;   // gain column of this lane (NX: kff)
+  ldouble *const gkdst = lane <= NX ? (lane < NX ? sK + lane : skf) : gdummy;
+  const int gkstr = lane < NX ? NX : (lane == NX ? 1 : 0);
   if constexpr (!FAST && !DDFAST) fetch_stage(N - 1);
   for (int k = (FAST || DDFAST) ? -1 : N - 1; k >= 0; k--) {
     // -- the image of stage k+1 is complete: it leaves for the gain record (read now, stored after the
@@ -2036,10 +2074,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       kpv[u] = img[e < KPW ? e : 0];
     }
 #pragma unroll
-    for (int u = 0; u < RPL; u++) {
-      const int e = lane + LPI * u;
-      if (e < C::RS) srec[e] = recv[u];
-    }
+    for (int u = 0; u < RPL; u++) *gsrdst[u] = recv[u];
     if (k > 0) fetch_stage(k - 1);  // travels while this stage is computed
     WSYNC();
     if (k < N - 1) {
@@ -2053,60 +2088,48 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       } else {
         gdouble *const kp1 = kpb + (size_t)(k + 1) * kps;
 #pragma unroll
-        for (int u = 0; u < KPL; u++) {
-          const int e = lane + LPI * u;
-          if (e < KPW) kp1[e] = kpv[u];
-        }
+        for (int u = 0; u < KPL; u++) kp1[lane + LPI * u < KPW ? lane + LPI * u : KPW] = kpv[u];   // (KPW: the record's spare word)
       }
     }
     if constexpr (!DD) {
       // Holonomic chain: A = [I hI; 0 I], B = [h2 I; h I].  The dense stage Hessian is formed in one step
       // from the record blocks and [A|B]^T P [A|B] in closed form (each entry from at most four entries of
       // P: blocks 11, 12, 21, 22 at (ii, jj)); rc of the stage goes into the image (stage N-1: finite, unused).
+      // Straight-line phases: what an entry is made of and where it goes are loop-invariant per-lane constants
+      // (go*), every read of a phase is issued before its first use, every store is unconditional (idle lanes write
+      // to gdummy) -- as for the fused kernel's paths above; same arithmetic per entry.
       const bool rec_cost = k < N - 1;   // a cost-to-go of stage k+1 exists
+      {
+        double r0[EPL], r1[EPL], a11[EPL], a12[EPL], a21[EPL], a22[EPL], pr[NX], rcl[NX];
 #pragma unroll
-      for (int u = 0; u < EPL; u++) {
-        const int e = lane + LPI * u;
-        double v = srec[qp[u]] - cwt * srec[cp[u]];
-        if (e < NV * NV) {
-          const int i = e / NV, j = e - i * NV;
-          // row / column kind: 0 = q, 1 = v, 2 = u, 3 = slack (no contribution)
-          const int ki = i < NQ ? 0 : (i < NX ? 1 : (i >= NX + NS ? 2 : 3));
-          const int kj = j < NQ ? 0 : (j < NX ? 1 : (j >= NX + NS ? 2 : 3));
-          if (rec_cost && ki != 3 && kj != 3) {
-            const int ii = ki == 0 ? i : (ki == 1 ? i - NQ : i - NX - NS);
-            const int jj = kj == 0 ? j : (kj == 1 ? j - NQ : j - NX - NS);
-            const double p11 = sP[ii * NX + jj], p12 = sP[ii * NX + NQ + jj];
-            const double p21 = sP[(NQ + ii) * NX + jj], p22 = sP[(NQ + ii) * NX + NQ + jj];
-            // left factor: row kind picks the combination of the two block rows
-            //   q: (r1, r2) = (1, 0); v: (h, 1); u: (h2, h)       (rows of [A|B]^T)
-            const double l1 = ki == 0 ? 1.0 : (ki == 1 ? h : h2), l2 = ki == 0 ? 0.0 : (ki == 1 ? 1.0 : h);
-            const double c1 = kj == 0 ? 1.0 : (kj == 1 ? h : h2), c2 = kj == 0 ? 0.0 : (kj == 1 ? 1.0 : h);
-            // sum_{a,b in {1,2}} l_a c_b P_ab
-            v += l1 * (c1 * p11 + c2 * p12) + l2 * (c1 * p21 + c2 * p22);
-          }
-          sQ[e] = v;
+        for (int u = 0; u < EPL; u++) {
+          r0[u] = srec[qp[u]]; r1[u] = srec[cp[u]];
+          a11[u] = sP[go11[u]]; a12[u] = sP[go11[u] + NQ]; a21[u] = sP[go11[u] + NQ * NX]; a22[u] = sP[go11[u] + NQ * NX + NQ];
         }
-      }
-      if (lane < NX) {
-        src[lane] = srec[C::R_RC + lane];
-        if (rec_cost) {
-          double s = sp[lane];
 #pragma unroll
-          for (int l = 0; l < NX; l++) s += sP[lane * NX + l] * srec[C::R_RC + l];
-          sPc[lane] = s;
+        for (int l = 0; l < NX; l++) { pr[l] = sP[glr * NX + l]; rcl[l] = srec[C::R_RC + l]; }
+        const double rcme = srec[C::R_RC + glr];
+        double pcs = sp[glr];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < EPL; u++) {
+          double v = r0[u] - cwt * r1[u];
+          const double add = gl1[u] * (gc1[u] * a11[u] + gc2[u] * a12[u]) + gl2[u] * (gc1[u] * a21[u] + gc2[u] * a22[u]);
+          v = (rec_cost && gon[u]) ? v + add : v;
+          *gqdst[u] = v;
         }
+#pragma unroll
+        for (int l = 0; l < NX; l++) pcs += pr[l] * rcl[l];
+        *gsrc = rcme;
+        *gpcdst = pcs;     // (stage N-1: P = 0, p = 0 -- the product is not used)
       }
       WSYNC();
-      if (lane < NV) {
-        double v = srec[C::R_Q0 + lane] - mu * srec[C::R_Q1 + lane];
-        const int ki = lane < NQ ? 0 : (lane < NX ? 1 : (lane >= NX + NS ? 2 : 3));
-        if (rec_cost && ki != 3) {
-          const int ii = ki == 0 ? lane : (ki == 1 ? lane - NQ : lane - NX - NS);
-          const double l1 = ki == 0 ? 1.0 : (ki == 1 ? h : h2), l2 = ki == 0 ? 0.0 : (ki == 1 ? 1.0 : h);
-          v += l1 * sPc[ii] + l2 * sPc[NQ + ii];
-        }
-        sq[lane] = v;
+      {
+        const double q0v = srec[C::R_Q0 + glv], q1v = srec[C::R_Q1 + glv], pc1 = sPc[giq], pc2 = sPc[NQ + giq];
+        __builtin_amdgcn_sched_barrier(0);
+        double v = q0v - mu * q1v;
+        v = (rec_cost && gqon) ? v + (gl1q * pc1 + gl2q * pc2) : v;
+        *gsqdst = v;
       }
       WSYNC();
     } else {
@@ -2162,11 +2185,20 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       WSYNC();
       }
     }
-    // -- Cholesky of Qww: every lane factors the small block in registers --------------------------
+    // -- Cholesky of Qww: every lane factors the small block in registers (its entries and the lane's right-hand
+    //    side are requested first, all at once) -----------------------------------------------------------------
+    double qw[NW][NW], colv[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++)
+#pragma unroll
+      for (int i = j; i < NW; i++) qw[i][j] = sQ[(NX + i) * NV + NX + j];
+#pragma unroll
+    for (int i = 0; i < NW; i++) colv[i] = glc < NX ? sQ[(NX + i) * NV + glc] : sq[NX + i];
+    __builtin_amdgcn_sched_barrier(0);
     double L[NW][NW], invd[NW];
 #pragma unroll
     for (int j = 0; j < NW; j++) {
-      double dg = sQ[(NX + j) * NV + NX + j];
+      double dg = qw[j][j];
 #pragma unroll
       for (int l = 0; l < j; l++) dg -= L[j][l] * L[j][l];
       if (!(dg > 0.0)) chol_ok = false;
@@ -2178,25 +2210,21 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       invd[j] = inv;
 #pragma unroll
       for (int i = j + 1; i < NW; i++) {
-        double s = sQ[(NX + i) * NV + NX + j];
+        double s = qw[i][j];
 #pragma unroll
         for (int l = 0; l < j; l++) s -= L[i][l] * L[j][l];
         L[i][j] = s * inv;
       }
     }
-    // -- gains: lane c < NX solves for column c of K, lane NX for kff -----------------------------------
-    if (lane <= NX) {
+    // -- gains: lane c < NX solves for column c of K, lane NX for kff (the other lanes solve column 0 again and
+    //    store to gdummy) ---------------------------------------------------------------------------------------
+    {
       double col[NW];
 #pragma unroll
-      for (int i = 0; i < NW; i++) col[i] = (lane < NX) ? -sQ[(NX + i) * NV + lane] : -sq[NX + i];
+      for (int i = 0; i < NW; i++) col[i] = -colv[i];
       chol_solve<NW>(L, invd, col);
-      if (lane < NX) {
 #pragma unroll
-        for (int i = 0; i < NW; i++) sK[i * NX + lane] = col[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < NW; i++) skf[i] = col[i];
-      }
+      for (int i = 0; i < NW; i++) gkdst[i * gkstr] = col[i];
     }
     WSYNC();
     // -- cost-to-go: P = sym(Qxx + Qxw K), p = qx + Qxw kff ---------------------------------------------
@@ -2448,16 +2476,26 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     }
   };
   if (!SLOTS && N > 1) fetch_fwd(1);
+  // (straight-line stages as in the backward pass: clamped per-lane rows, reads before the first use, idle lanes
+  //  store to gdummy; the two stores of the step to global memory stay predicated)
+  const bool fisw = lane < NW, fact = lane < NW + NX;
+  const int fi = fisw ? lane : (fact ? lane - NW : 0);
+  const int foff = fisw ? (NW * NX + lane) : (NW * NX + NW + NP2 + fi);
+  int frow[NX];
+#pragma unroll
+  for (int j = 0; j < NX; j++) frow[j] = fisw ? (lane * NX + j) : (NW * NX + NW + tri(fi, j));
+  ldouble *const fdwdst = fisw ? sdw + lane : gdummy;
+  ldouble *fimg[KPL];
+#pragma unroll
+  for (int u = 0; u < KPL; u++) fimg[u] = lane + LPI * u < KPW ? img + lane + LPI * u : gdummy;
+  const bool fisq = glr < NQ;
   for (int k = 0; k < N; k++) {
     // image of this stage: stage 0's is still in the work area; later ones come back from the gain record
     // (copied into the work area), or are read where the backward pass left them (SLOTS)
     const ldouble *const im = (SLOTS && (k > 0 || FAST)) ? slots + (size_t)k * GS : img;
-    if (!SLOTS && k > 0) {
+    if (!SLOTS) {
 #pragma unroll
-      for (int u = 0; u < KPL; u++) {
-        const int e = lane + LPI * u;
-        if (e < KPW) img[e] = fv[u];
-      }
+      for (int u = 0; u < KPL; u++) *(k > 0 ? fimg[u] : gdummy) = fv[u];
     }
     if constexpr (DD) {
       if (k < N - 1) {   // [A|B] of stage k straight from its record (diff-drive only)
@@ -2472,50 +2510,45 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     if (!SLOTS && k > 0 && k < N - 1) fetch_fwd(k + 1);
     WSYNC();
     // (the defect of the stage, read before the step of the stage may overwrite it: SLOTS)
-    const double rcv = im[NW * NX + NW + NP2 + NX + (lane < NX ? lane : 0)];
+    const double rcv = im[NW * NX + NW + NP2 + NX + glr];
     // dw = kff + K dx (lanes < NW) and nu+ = p + P dx (the next NX lanes) as ONE instruction stream: both
     // are "offset + row . dx" over the image, only the per-lane addresses differ (LDS instruction count
     // is what bounds this kernel when the whole batch iterates)
-    double dzv = 0.0;
-    if (lane < NW + NX) {
-      const bool isw = lane < NW;
-      const int i = isw ? lane : lane - NW;
-      double s = im[isw ? (NW * NX + lane) : (NW * NX + NW + NP2 + i)];
+    double dxv[NX], rowv[NX];
 #pragma unroll
-      for (int j = 0; j < NX; j++) s += im[isw ? (lane * NX + j) : (NW * NX + NW + tri(i, j))] * sdx[j];
-      if (isw) {
-        sdw[lane] = s;
-        dzv = s;
-      } else {
-        dzv = sdx[i];
-        if (k >= 1) so.nunew[(size_t)i * so.SS + (size_t)k * so.KS] = s;
-      }
-    }
+    for (int j = 0; j < NX; j++) { dxv[j] = sdx[j]; rowv[j] = im[frow[j]]; }
+    double sacc = im[foff];
+    const double dxi = sdx[fi < NX ? fi : 0];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NX; j++) sacc += rowv[j] * dxv[j];
+    *fdwdst = sacc;
+    const double dzv = fisw ? sacc : dxi;
+    if (fact && !fisw && k >= 1) so.nunew[(size_t)fi * so.SS + (size_t)k * so.KS] = sacc;
     // dz of the stage in one request: lanes < NW hold dw (slots NX..), the next NX lanes dx (slots 0..)
-    if (lane < NW + NX) so.dz[(size_t)(lane < NW ? NX + lane : lane - NW) * so.SS + (size_t)k * so.KS] = dzv;
+    if (fact) so.dz[(size_t)(fisw ? NX + lane : lane - NW) * so.SS + (size_t)k * so.KS] = dzv;
     WSYNC();
     double dxn = 0.0;
-    if (k < N - 1 && lane < NX) {
-      if constexpr (!DD) {
-        // holonomic chain, closed form of rc + [A|B][dx; dw] (same order of the non-zero terms as the dense
-        // product): q rows dx_i + h dx_{n+i} + h2 dw_i, v rows dx_i + h dw_{i-n}
-        const bool isq = lane < NQ;
-        double s = rcv;
-        s += sdx[lane];
-        s += (isq ? h : 0.0) * sdx[isq ? NQ + lane : lane];
-        s += (isq ? h2 : h) * sdw[NS + (isq ? lane : lane - NQ)];
-        dxn = s;
-      } else {
-        double s = rcv;
+    if constexpr (!DD) {
+      // holonomic chain, closed form of rc + [A|B][dx; dw] (same order of the non-zero terms as the dense
+      // product): q rows dx_i + h dx_{n+i} + h2 dw_i, v rows dx_i + h dw_{i-n}
+      const double d0 = sdx[glr], d1 = sdx[fisq ? NQ + glr : glr], w0 = sdw[NS + (fisq ? glr : glr - NQ)];
+      __builtin_amdgcn_sched_barrier(0);
+      double sx = rcv;
+      sx += d0;
+      sx += (fisq ? h : 0.0) * d1;
+      sx += (fisq ? h2 : h) * w0;
+      dxn = sx;
+    } else {
+      double sx = rcv;
 #pragma unroll
-        for (int j = 0; j < NX; j++) s += sAB[lane * NV + j] * sdx[j];
+      for (int j = 0; j < NX; j++) sx += sAB[glr * NV + j] * sdx[j];
 #pragma unroll
-        for (int j = 0; j < NW; j++) s += sAB[lane * NV + NX + j] * sdw[j];
-        dxn = s;
-      }
+      for (int j = 0; j < NW; j++) sx += sAB[glr * NV + NX + j] * sdw[j];
+      dxn = sx;
     }
     // (all lanes have issued their reads of sdx before this store: same wavefront, program order)
-    if (k < N - 1 && lane < NX) sdx[lane] = dxn;
+    *((k < N - 1 && lane < NX) ? sdx + lane : gdummy) = dxn;
     // (next iteration's barrier orders this write before the reads)
   }
   return true;
@@ -4344,7 +4377,7 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
     W.grow[i] = c.take<double>(S * (M.nh > 0 ? M.nh : 1));
     W.Jq[i] = c.take<double>(S * (M.nfk > 0 ? M.nfk * nq : 1));
   }
-  W.kps = (M.nw * M.nx + M.nw + M.nx * (M.nx + 1) / 2 + M.nx + M.nx + 7) / 8 * 8;
+  W.kps = (M.nw * M.nx + M.nw + M.nx * (M.nx + 1) / 2 + M.nx + M.nx + 8) / 8 * 8;   // (>= one spare word behind the image: stores of idle lanes)
   W.KP = c.take<double>(S * W.kps);
   W.part = c.take<double>(S * P_COUNT);
   W.gphi = c.take<double>(S);
@@ -4475,7 +4508,7 @@ static size_t carve_fused(const DevModel &M, int Bcap, void *base, FusedWs &F) {
   F.wmu = c.take<double>(Bcap);
   F.rs = rec_layout(M).rs;
   F.R = c.take<double>((size_t)Bcap * M.N * F.rs);
-  F.kps = (M.nw * M.nx + M.nw + M.nx * (M.nx + 1) / 2 + M.nx + M.nx + 7) / 8 * 8;
+  F.kps = (M.nw * M.nx + M.nw + M.nx * (M.nx + 1) / 2 + M.nx + M.nx + 8) / 8 * 8;
   F.KP = c.take<double>((size_t)Bcap * M.N * F.kps);
   F.passes = c.take<int>(64);
   F.lastp = c.take<int>(Bcap);

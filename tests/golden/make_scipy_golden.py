@@ -96,21 +96,31 @@ def main():
     out = {}
     for name, B, seed in CASES:
         sc = _scenario(name)
+        # the inputs are the scenario generator's (same seed): a hash pins them, the test regenerates them.  Of the 64
+        # SLSQP solutions only the first stage (the applied control) and the objective are kept: the fixture stays small.
         r = [results[("slsqp", name, b)] for b in range(B)]
-        out.update({name + "_xinit": sc.xinit, name + "_x0": sc.x0, name + "_params": sc.params,
-                    name + "_z": np.array([x["z"] for x in r]), name + "_status": np.array([x["status"] for x in r], dtype=np.int32),
+        out.update({name + "_inputs_sha256": np.array(inputs_sha(sc)), name + "_seed": np.array([seed]),
+                    name + "_z1": np.array([x["z"][0] for x in r]), name + "_status": np.array([x["status"] for x in r], dtype=np.int32),
                     name + "_fun": np.array([x["fun"] for x in r]), name + "_nit": np.array([x["nit"] for x in r], dtype=np.int32),
-                    name + "_viol": np.array([x["viol"] for x in r]), name + "_seed": np.array([seed])})
+                    name + "_viol": np.array([x["viol"] for x in r])})
         t = [results[("tc", name, b)] for b in range(N_TC[name])]
-        out.update({name + "_tc_z": np.array([x["z"] for x in t]), name + "_tc_fun": np.array([x["fun"] for x in t]),
+        out.update({name + "_tc_z1": np.array([x["z"][0] for x in t]), name + "_tc_fun": np.array([x["fun"] for x in t]),
                     name + "_tc_viol": np.array([x["viol"] for x in t]), name + "_tc_status": np.array([x["status"] for x in t], dtype=np.int32)})
         lp = results[("loop", name, 0)]
-        out.update({name + "_loop_x": lp["x"], name + "_loop_z": lp["z"], name + "_loop_fun": lp["fun"]})
+        out.update({name + "_loop_x": lp["x"], name + "_loop_z1": lp["z"][:, 0], name + "_loop_fun": lp["fun"]})
     h = [results[("heun", "cfg3", b)] for b in range(N_HEUN)]
-    out.update({"cfg3_heun_z": np.array([x["z"] for x in h]), "cfg3_heun_fun": np.array([x["fun"] for x in h]),
+    out.update({"cfg3_heun_z1": np.array([x["z"][0] for x in h]), "cfg3_heun_fun": np.array([x["fun"] for x in h]),
                 "cfg3_heun_viol": np.array([x["viol"] for x in h])})
     np.savez_compressed(OUT, **out)
     print("wrote", OUT)
+
+
+def inputs_sha(sc) -> str:
+    import hashlib
+    hsh = hashlib.sha256()
+    for a in (sc.xinit, sc.x0, sc.params):
+        hsh.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+    return hsh.hexdigest()
 
 
 if __name__ == "__main__":
