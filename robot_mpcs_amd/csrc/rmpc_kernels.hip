@@ -672,7 +672,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
     ln[IDXL(i)] = lv;
     const double rg = g - tv;
     theta += fabs(rg);
-    if (!(tv > 0.0)) bad = 1;   // (cannot happen: fraction to the boundary; keeps the product's sign meaningful)
+    bad |= (int)!(tv > 0.0);   // (cannot happen: fraction to the boundary; keeps the product's sign meaningful.  |=: no branch)
     {
       int ex;
       lprod *= frexp(tv, &ex);
@@ -705,7 +705,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         const double wi = Bv.wi[u];
         const bool on = (wi != 0.0) && !(k == 0 && j < NX);
         const double cN = (double)M.N * wi;
-        if (on && !(h > 0.0)) bad = 1;
+        bad |= (int)(on & !(h > 0.0));   // (bitwise: a short-circuit branch would cut the rows into separate basic blocks)
         const double ih = frcp(h);
         f += on ? cN * ih : 0.0;
         gf[j] += on ? -cN * (ih * ih) * sg : 0.0;
@@ -723,14 +723,16 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
       double gdz = sg * dzo[j];
       if constexpr (NS > 0) { if (soft) { gold += zo[NX]; gdz += dzo[NX]; } }
       const RowW rw = row_core(i, g, Bv.tcv[u], Bv.lcv[u], gold, gdz);
-      if (neutral) continue;
-      q0[j] += sg * rw.ca;
-      q1[j] += sg * rw.cb;
-      rs[j] -= sg * rw.lv;
+      // (a neutralised row contributes nothing; by selection, not by a branch: in the fused kernel the stage differs
+      //  from lane to lane and a divergent `continue` cuts the rows of a variable into exec-masked blocks)
+      q0[j] = neutral ? q0[j] : q0[j] + sg * rw.ca;
+      q1[j] = neutral ? q1[j] : q1[j] + sg * rw.cb;
+      rs[j] = neutral ? rs[j] : rs[j] - sg * rw.lv;
+      const double sigc = neutral ? 0.0 : rw.sig;
       if (j < NQ) {
-        if constexpr (QLDS) qacc[qtri(j < NQ ? j : 0, j < NQ ? j : 0) * kSweepBlock] += rw.sig;
-        else Qqq[j < NQ ? j : 0][j < NQ ? j : 0] += rw.sig;
-      } else Dg[j] += rw.sig;
+        if constexpr (QLDS) qacc[qtri(j < NQ ? j : 0, j < NQ ? j : 0) * kSweepBlock] += sigc;
+        else Qqq[j < NQ ? j : 0][j < NQ ? j : 0] = neutral ? Qqq[j < NQ ? j : 0][j < NQ ? j : 0] : Qqq[j < NQ ? j : 0][j < NQ ? j : 0] + rw.sig;
+      } else Dg[j] = neutral ? Dg[j] : Dg[j] + rw.sig;
       if constexpr (NS > 0) {
         if (soft) {
           cs[j] += rw.sig * sg;
@@ -916,7 +918,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         const double wi = Bf.wi;
         const bool on = (wi != 0.0) && (k != 0);   // (selects: see the single-variable rows)
         const double cN = (double)M.N * wi;
-        if (on && !(h > 0.0)) bad = 1;
+        bad |= (int)(on & !(h > 0.0));   // (bitwise: a short-circuit branch would cut the rows into separate basic blocks)
         const double ih = frcp(h);
         f += on ? cN * ih : 0.0;
         const double c1 = on ? -cN * (ih * ih) : 0.0, c2 = on ? 2.0 * cN * (ih * ih * ih) : 0.0;
@@ -1142,7 +1144,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
   }
   rec[C::R_ZERO] = 0.0;
   const double logsum = log(lprod) + 0.6931471805599453094 * (double)lexp;
-  if (!isfinite(f) || !isfinite(theta) || !isfinite(logsum)) bad = 1;
+  bad |= (int)(!isfinite(f) | !isfinite(theta) | !isfinite(logsum));
   SW_STAMP(3);
   out.f = f; out.th = theta; out.logs = logsum; out.rstat = rstat; out.req = req; out.rineq = rineq;
   out.rcomp = rcomp; out.sumc = sumc; out.minc = minc; out.bad = (double)bad;
@@ -2925,49 +2927,67 @@ __device__ __forceinline__ void step_body(const V &v, const StepIO<RP> &io, cons
     (void)i;  // the steps themselves are not stored: the sweep recomputes them from the same inputs
     // ratio tests with Newton reciprocals (the quotient of a non-negative step is discarded by the select)
     const double rp = -kTau * tv * frcp(dt), rd = -kTau * lv * frcp(dl);
-    ap = (dt < 0 && rp < ap) ? rp : ap;
-    ad = (dl < 0 && rd < ad) ? rd : ad;
+    // (bitwise and: no short-circuit branch -- the rows of a stage stay one basic block)
+    ap = ((dt < 0) & (rp < ap)) ? rp : ap;
+    ad = ((dl < 0) & (rd < ad)) ? rd : ad;
     gphi -= mu * dt * itv;
   };
-  // FK rows
-  auto fk_row_body = [&](const int r) __attribute__((always_inline)) {
+  // Every request of the phase leaves before the first row is evaluated (one wavefront per SIMD hides no latency by
+  // itself; left where the arithmetic is, the compiler waits for each small group of loads in turn: a dozen round
+  // trips to L2 per call instead of one).  The rows are then evaluated in the old order (the merit slope is a sum).
+  struct FkIn { double g, tv, lv, jq[NQ]; };
+  auto fk_load = [&](const int r, FkIn &f) __attribute__((always_inline)) {
     const int i = v.fk_row(r), fi = v.fk_idx(r);
-    const double g = grow[IDXL(i)], tv = tc[IDXL(i)], lv = lc[IDXL(i)];
-    double jq[NQ];
+    f.g = grow[IDXL(i)]; f.tv = tc[IDXL(i)]; f.lv = lc[IDXL(i)];
 #pragma unroll
-    for (int a = 0; a < NQ; a++) jq[a] = Jq[IDXL(fi * NQ + a)];
+    for (int a = 0; a < NQ; a++) f.jq[a] = Jq[IDXL(fi * NQ + a)];
+  };
+  auto fk_row_body = [&](const int r, const FkIn &f) __attribute__((always_inline)) {
     double gdz = 0.0;
 #pragma unroll
-    for (int a = 0; a < NQ; a++) gdz += jq[a] * dz[a];
+    for (int a = 0; a < NQ; a++) gdz += f.jq[a] * dz[a];
     if constexpr (NS > 0) gdz += dz[NX];
-    row(i, gdz, g, tv, lv);
+    row(v.fk_row(r), gdz, f.g, f.tv, f.lv);
   };
+  constexpr int NFKC = []() { if constexpr (V::SPEC) return V::nfkrows() > 0 ? V::nfkrows() : 1; else return 1; }();
+  FkIn fkin[NFKC];
   if constexpr (V::SPEC) {
-    for_range<0, V::nfkrows()>([&](auto rc) __attribute__((always_inline)) { fk_row_body(decltype(rc)::value); });
-  } else {
-    for (int r = 0; r < v.nfkrows(); r++) fk_row_body(r);
+    for_range<0, V::nfkrows()>([&](auto rc) __attribute__((always_inline)) { fk_load(decltype(rc)::value, fkin[decltype(rc)::value]); });
   }
   // single-variable rows, by variable (unconditional clamped requests, see sweep_body)
+  double tvv[NV][kVarRows], lvv[NV][kVarRows], glv[NV][kVarRows];
 #pragma unroll
   for (int j = 0; j < NV; j++) {
-    double tv[kVarRows], lv[kVarRows], gv[kVarRows];
 #pragma unroll
     for (int u = 0; u < kVarRows; u++) {
       const int i = v.v_row(j, u);
       const int ii = i >= 0 ? i : 0;
       const bool general = v.v_poff(j, u) >= 0;
-      tv[u] = tc[IDXL(ii)];
-      lv[u] = lc[IDXL(ii)];
-      const double gl = grow[IDXL(general ? ii : 0)];
-      gv[u] = general ? gl : ((k == 0 && j < NX) ? 1.0 : (double)v.v_sgn(j, u) * (z[j] - v.v_val(j, u)));
+      tvv[j][u] = tc[IDXL(ii)];
+      lvv[j][u] = lc[IDXL(ii)];
+      glv[j][u] = grow[IDXL(general ? ii : 0)];
     }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (V::SPEC) {
+    for_range<0, V::nfkrows()>([&](auto rc) __attribute__((always_inline)) { fk_row_body(decltype(rc)::value, fkin[decltype(rc)::value]); });
+  } else {
+    for (int r = 0; r < v.nfkrows(); r++) {
+      fk_load(r, fkin[0]);
+      fk_row_body(r, fkin[0]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
 #pragma unroll
     for (int u = 0; u < kVarRows; u++) {
       const int i = v.v_row(j, u);
       if (i < 0) continue;
+      const bool general = v.v_poff(j, u) >= 0;
+      const double gvv = general ? glv[j][u] : ((k == 0 && j < NX) ? 1.0 : (double)v.v_sgn(j, u) * (z[j] - v.v_val(j, u)));
       double gdz = (double)v.v_sgn(j, u) * dz[j];
       if constexpr (NS > 0) { if (v.v_soft(j, u)) gdz += dz[NX]; }
-      row(i, gdz, gv[u], tv[u], lv[u]);
+      row(i, gdz, gvv, tvv[j][u], lvv[j][u]);
     }
   }
   ap_out = ap; ad_out = ad; gphi_out = gphi;
