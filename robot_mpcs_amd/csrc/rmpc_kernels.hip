@@ -983,9 +983,23 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         if constexpr (r >= V::slot_row_begin(SL) && r < V::slot_row_begin(SL + 1)) fk_row_body(r, fkb[r]);
       });
     } else {
-      for (int r = v.slot_row_begin(SL); r < v.slot_row_begin(SL + 1); r++) {
-        fk_load(r, fkb[0]);   // requests first, arithmetic after
-        fk_row_body(r, fkb[0]);
+      // (runtime tables: the requests of the next row of the slot leave before this row's arithmetic)
+      const int rb0 = v.slot_row_begin(SL), re0 = v.slot_row_begin(SL + 1);
+      if constexpr (C::FKCURV) {
+        // (the arms: no register to spare for a second row's inputs -- 420 -> 564 B of scratch, sweep 98 -> 102 us)
+        for (int r = rb0; r < re0; r++) {
+          fk_load(r, fkb[0]);   // requests first, arithmetic after
+          fk_row_body(r, fkb[0]);
+        }
+      } else if (rb0 < re0) {
+        FkBuf nxt;
+        fk_load(rb0, nxt);
+        for (int r = rb0; r < re0; r++) {
+          fkb[0] = nxt;
+          fk_load(r + 1 < re0 ? r + 1 : r, nxt);
+          __builtin_amdgcn_sched_barrier(0);
+          fk_row_body(r, fkb[0]);
+        }
       }
     }
     if constexpr (C::FKCURV) {
@@ -2954,42 +2968,70 @@ __device__ __forceinline__ void step_body(const V &v, const StepIO<RP> &io, cons
   if constexpr (V::SPEC) {
     for_range<0, V::nfkrows()>([&](auto rc) __attribute__((always_inline)) { fk_load(decltype(rc)::value, fkin[decltype(rc)::value]); });
   }
-  // single-variable rows, by variable (unconditional clamped requests, see sweep_body)
-  double tvv[NV][kVarRows], lvv[NV][kVarRows], glv[NV][kVarRows];
+  // single-variable rows, by variable (unconditional clamped requests, see sweep_body), in chunks of VCH variables whose
+  // requests leave together: all of them for the small models, one variable at a time for the arms (12 requests per
+  // variable: more in flight cost the arm's kernel registers it does not have -- k_step 30 -> 33 us with six)
+  constexpr int VCH = NV <= 12 ? NV : 1;
+  double tvv[VCH][kVarRows], lvv[VCH][kVarRows], glv[VCH][kVarRows];
+  auto chunk_load = [&](auto c0c) __attribute__((always_inline)) {
+    constexpr int c0 = decltype(c0c)::value;
 #pragma unroll
-  for (int j = 0; j < NV; j++) {
+    for (int jj = 0; jj < VCH; jj++) {
+      const int j = c0 + jj < NV ? c0 + jj : NV - 1;
 #pragma unroll
-    for (int u = 0; u < kVarRows; u++) {
-      const int i = v.v_row(j, u);
-      const int ii = i >= 0 ? i : 0;
-      const bool general = v.v_poff(j, u) >= 0;
-      tvv[j][u] = tc[IDXL(ii)];
-      lvv[j][u] = lc[IDXL(ii)];
-      glv[j][u] = grow[IDXL(general ? ii : 0)];
+      for (int u = 0; u < kVarRows; u++) {
+        const int i = v.v_row(j, u);
+        const int ii = i >= 0 ? i : 0;
+        const bool general = v.v_poff(j, u) >= 0;
+        tvv[jj][u] = tc[IDXL(ii)];
+        lvv[jj][u] = lc[IDXL(ii)];
+        glv[jj][u] = grow[IDXL(general ? ii : 0)];
+      }
     }
-  }
+  };
+  auto chunk_rows = [&](auto c0c) __attribute__((always_inline)) {
+    constexpr int c0 = decltype(c0c)::value;
+#pragma unroll
+    for (int jj = 0; jj < VCH; jj++) {
+      const int j = c0 + jj;
+      if (j >= NV) continue;
+#pragma unroll
+      for (int u = 0; u < kVarRows; u++) {
+        const int i = v.v_row(j, u);
+        if (i < 0) continue;
+        const bool general = v.v_poff(j, u) >= 0;
+        const double gvv = general ? glv[jj][u] : ((k == 0 && j < NX) ? 1.0 : (double)v.v_sgn(j, u) * (z[j] - v.v_val(j, u)));
+        double gdz = (double)v.v_sgn(j, u) * dz[j];
+        if constexpr (NS > 0) { if (v.v_soft(j, u)) gdz += dz[NX]; }
+        row(i, gdz, gvv, tvv[jj][u], lvv[jj][u]);
+      }
+    }
+  };
+  chunk_load(std::integral_constant<int, 0>{});
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (V::SPEC) {
     for_range<0, V::nfkrows()>([&](auto rc) __attribute__((always_inline)) { fk_row_body(decltype(rc)::value, fkin[decltype(rc)::value]); });
   } else {
-    for (int r = 0; r < v.nfkrows(); r++) {
-      fk_load(r, fkin[0]);
-      fk_row_body(r, fkin[0]);
+    // (runtime tables: four rows' requests at a time, clamped to the last row; the row count is uniform)
+    const int nfk = v.nfkrows();
+    constexpr int FCH = NV <= 12 ? 4 : 1;
+    for (int r0 = 0; r0 < nfk; r0 += FCH) {
+      FkIn f4[FCH];
+#pragma unroll
+      for (int u = 0; u < FCH; u++) fk_load(r0 + u < nfk ? r0 + u : nfk - 1, f4[u]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < FCH; u++)
+        if (r0 + u < nfk) fk_row_body(r0 + u, f4[u]);
     }
   }
-#pragma unroll
-  for (int j = 0; j < NV; j++) {
-#pragma unroll
-    for (int u = 0; u < kVarRows; u++) {
-      const int i = v.v_row(j, u);
-      if (i < 0) continue;
-      const bool general = v.v_poff(j, u) >= 0;
-      const double gvv = general ? glv[j][u] : ((k == 0 && j < NX) ? 1.0 : (double)v.v_sgn(j, u) * (z[j] - v.v_val(j, u)));
-      double gdz = (double)v.v_sgn(j, u) * dz[j];
-      if constexpr (NS > 0) { if (v.v_soft(j, u)) gdz += dz[NX]; }
-      row(i, gdz, gvv, tvv[j][u], lvv[j][u]);
-    }
-  }
+  chunk_rows(std::integral_constant<int, 0>{});
+  for_range<1, (NV + VCH - 1) / VCH>([&](auto cc) __attribute__((always_inline)) {
+    constexpr int c0 = decltype(cc)::value * VCH;
+    chunk_load(std::integral_constant<int, c0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    chunk_rows(std::integral_constant<int, c0>{});
+  });
   ap_out = ap; ad_out = ad; gphi_out = gphi;
 }
 
