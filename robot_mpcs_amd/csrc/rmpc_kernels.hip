@@ -1284,6 +1284,30 @@ __device__ __forceinline__ double wave_min(double v) {
   return v;
 }
 
+// Several reductions at once, step by step: the exchanges of one step of all of them are issued together (a single
+// reduction is a chain of dependent LDS-crossbar round trips; done one after the other, eleven of them cost eleven
+// chains).  Same partner pattern, hence the same rounding, as wave_sum / wave_max / wave_min.
+template <int LPI, int NS_, int NM_, int NN_>
+__device__ __forceinline__ void wave_reduce_many(double (&sums)[NS_], double (&maxs)[NM_], double (&mins)[NN_]) {
+#pragma unroll
+  for (int off = LPI / 2; off >= 1; off >>= 1) {
+    double ts[NS_], tm[NM_], tn[NN_];
+#pragma unroll
+    for (int i = 0; i < NS_; i++) ts[i] = __shfl_xor(sums[i], off, 64);
+#pragma unroll
+    for (int i = 0; i < NM_; i++) tm[i] = __shfl_xor(maxs[i], off, 64);
+#pragma unroll
+    for (int i = 0; i < NN_; i++) tn[i] = __shfl_xor(mins[i], off, 64);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NS_; i++) sums[i] += ts[i];
+#pragma unroll
+    for (int i = 0; i < NM_; i++) maxs[i] = fmax(maxs[i], tm[i]);
+#pragma unroll
+    for (int i = 0; i < NN_; i++) mins[i] = fmin(mins[i], tn[i]);
+  }
+}
+
 // ---- per-instance solver state ------------------------------------------------------------------------
 // One set of words per instance.  The pass kernels keep them in the workspace (arrays over the batch), the
 // fused kernel in registers of the wavefront that owns the instance; the decision logic is the same code.
@@ -3236,7 +3260,11 @@ __device__ __noinline__ RMPC_ONE_WAVE SweepStepRes fused_sweep_step_call(const F
     io.dz = slots + DZ_OFF; io.SSd = 1; io.loffd = (unsigned)(k * GS);
     step_body<C, ldouble, V>(v, io, k, mu, ap, ad, gp);
   }
-  ap = wave_min<kFusedStages>(ap); ad = wave_min<kFusedStages>(ad); gp = wave_sum<kFusedStages>(gp);
+  {
+    double rs1[1] = {gp}, rm0[1] = {0.0}, rn2[2] = {ap, ad};
+    wave_reduce_many<kFusedStages>(rs1, rm0, rn2);
+    gp = rs1[0]; ap = rn2[0]; ad = rn2[1];
+  }
   SweepStepRes r;
   r.amin_p = fresh ? fmin(amin_p_in, ap) : amin_p_in;
   r.amin_d = fresh ? fmin(amin_d_in, ad) : amin_d_in;
@@ -3347,7 +3375,17 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) v
             // multipliers for a warm start of the next solve of this instance (a failed solve leaves zeros and mu0)
             const bool okd = (s.status == ST_ACTIVE || s.status >= 0) && isfinite(s.mu) && s.mu > 0.0;
             const gdouble *lf = Pe.pl[s.cur], *nf = Pe.pn[s.cur];
-            for (int i = 0; i < F.m; i++) Pe.pwl[i * S + k] = okd ? lf[i * S + k] : 0.0;
+            {
+              int i = 0;
+              for (; i + 8 <= F.m; i += 8) {   // (eight requests in flight, as for the parameters)
+                double lv8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) lv8[u] = lf[(i + u) * S + k];
+#pragma unroll
+                for (int u = 0; u < 8; u++) Pe.pwl[(i + u) * S + k] = okd ? lv8[u] : 0.0;
+              }
+              for (; i < F.m; i++) Pe.pwl[i * S + k] = okd ? lf[i * S + k] : 0.0;
+            }
 #pragma unroll
             for (int j = 0; j < NX; j++) Pe.pwn[j * S + k] = okd ? nf[j * S + k] : 0.0;
           }
@@ -3389,8 +3427,17 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) v
                 for (int j = 0; j < NV + NX; j++) slots[k * GS + DZ_OFF + j] = 0.0;
               }
               if (params) {
+                // (eight requests in flight: one by one the copy is npar dependent round trips to memory)
                 const double *pr = params + (b * N + k) * M.npar;
-                for (int j = 0; j < M.npar; j++) P0.pp[j * S + k] = pr[j];
+                int j = 0;
+                for (; j + 8 <= M.npar; j += 8) {
+                  double pv8[8];
+#pragma unroll
+                  for (int u = 0; u < 8; u++) pv8[u] = pr[j + u];
+#pragma unroll
+                  for (int u = 0; u < 8; u++) P0.pp[(j + u) * S + k] = pv8[u];
+                }
+                for (; j < M.npar; j++) P0.pp[j * S + k] = pr[j];
               }
             }
             inst_init(s, warm ? warm_mu(F.wmu[b], M.mu0) : M.mu0);
@@ -3481,10 +3528,12 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       if (fresh) { s.amin_p = ssr.amin_p; s.amin_d = ssr.amin_d; gphi_sum = ssr.gphi; }
     }
     Reduced r;
-    r.f = wave_sum<LPI>(q.f); r.th = wave_sum<LPI>(q.th); r.lgs = wave_sum<LPI>(q.logs); r.sumc = wave_sum<LPI>(q.sumc);
-    r.badf = wave_sum<LPI>(q.bad);
-    r.rstat = wave_max<LPI>(q.rstat); r.req = wave_max<LPI>(q.req); r.rineq = wave_max<LPI>(q.rineq);
-    r.rcomp = wave_max<LPI>(q.rcomp); r.minc = wave_min<LPI>(q.minc);
+    {
+      double rs5[5] = {q.f, q.th, q.logs, q.sumc, q.bad}, rm4[4] = {q.rstat, q.req, q.rineq, q.rcomp}, rn1[1] = {q.minc};
+      wave_reduce_many<LPI>(rs5, rm4, rn1);
+      r.f = rs5[0]; r.th = rs5[1]; r.lgs = rs5[2]; r.sumc = rs5[3]; r.badf = rs5[4];
+      r.rstat = rm4[0]; r.req = rm4[1]; r.rineq = rm4[2]; r.rcomp = rm4[3]; r.minc = rn1[0];
+    }
     r.gphi = first ? 0.0 : gphi_sum;
     GSYNC();   // trial point and records are complete before any lane reads another lane's part
     STAMP_B(st_sweep);
@@ -3542,7 +3591,11 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       step_body<C, RP, V>(v, io, k, s.mu, ap, ad, gp);
     }
     unpark();
-    ap = wave_min<LPI>(ap); ad = wave_min<LPI>(ad); gp = wave_sum<LPI>(gp);
+    {
+      double rs1[1] = {gp}, rm0[1] = {0.0}, rn2[2] = {ap, ad};
+      wave_reduce_many<LPI>(rs1, rm0, rn2);
+      gp = rs1[0]; ap = rn2[0]; ad = rn2[1];
+    }
     if (stepping) {
       s.amin_p = fmin(s.amin_p, ap);
       s.amin_d = fmin(s.amin_d, ad);
