@@ -174,7 +174,8 @@ struct Cfg {
   static constexpr int SWEEP_WPE = 1;
   // k_riccati: no register cap (94 VGPRs for the point robot) -- at 80 the recursion spills inside its stage
   // loop: -3 % throughput on cfg2, -20 % on cfg3 (measured); the arm at two wavefronts per SIMD (256 registers,
-  // 380 B scratch): 84 -> 154 us per launch of 1024 instances
+  // 380 B scratch): 84 -> 154 us per launch of 1024 instances in round 2; with round 3's recursion (300 registers
+  // uncapped; capped 256 + 108 B scratch): four batches in flight 0.497 -> 0.455 M solves/s, a lone batch 4.50 -> 4.61 ms
   static constexpr int RIC_WPE = 1;
   // lanes per instance in the grouped Riccati blocks: half a wavefront for the small models
   static constexpr int RIC_LPI = (NX + NS_ + NU <= 16) ? 32 : 64;

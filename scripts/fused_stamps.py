@@ -30,5 +30,3 @@ if sec[:, :4].sum() > 0:
     for i, name in enumerate(["top loads + trial point", "objective, kinematics, distance rows", "single-variable rows", "dynamics, records, log"]):
         print(f"     sweep / {name:38s} {sec[:, i].sum() / st[:, 5].sum():9.0f}")
 print(f"  total cycles per pass {tot.sum() / st[:, 5].sum():.0f}   (s_memtime: shader clock)")
-t0 = st[:, 6] - st[:, 6].min()
-print(f"  block start spread: median {np.median(t0):.0f} max {t0.max():.0f}; kernel span {(t0 + tot).max():.0f} ticks")

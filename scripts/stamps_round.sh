@@ -1,0 +1,10 @@
+#!/bin/bash
+# phase stamps of k_fused for the round's profile file (library built with: scripts/dev_build.sh 0x21 -DRMPC_STAMPS,
+# moved to csrc/librmpc_hip_stamps.so)       usage: scripts/stamps_round.sh > profiles/rNN_fused_phase_stamps.txt
+export RMPC_ALLOW_STALE=1 RMPC_LIB_PATH=$PWD/robot_mpcs_amd/csrc/librmpc_hip_stamps.so
+echo "# scripts/fused_stamps.py, library built with scripts/dev_build.sh 0x21 -DRMPC_STAMPS (s_memtime around the phases of k_fused; cycles per wavefront pass)"
+echo "## generated views (default): the step lengths are formed inside the sweep call, the step column is empty"
+python scripts/fused_stamps.py cfg2 4096 && python scripts/fused_stamps.py cfg2 128 || exit 1
+echo "## runtime tables (RMPC_NO_SPEC=1; the boxer always)"
+RMPC_NO_SPEC=1 python scripts/fused_stamps.py cfg2 4096 && RMPC_NO_SPEC=1 python scripts/fused_stamps.py cfg2 128 || exit 1
+python scripts/fused_stamps.py cfg3 4096 && python scripts/fused_stamps.py cfg3 128
