@@ -297,7 +297,7 @@ def cpu_baseline(leg, gpu_z, gpu_exit, Solver, make_scenario, local_rank):
     }
 
 
-def run_cfg5(args, fleet, dev, rank, world, dd, fence, steps, warmup):
+def run_cfg5(args, fleet, dev, rank, world, dd, fence, steps, warmup, cdev=None):
     """BASELINE configs[4] on this rank's shard: the device-resident closed loop (scene packing + solve + plant step +
     shifted plan + warm multipliers + goal hand-over), timed like the headline (barrier + synchronize on both sides,
     max over ranks).  A STEADY loop: no episodes, no resets of the fleet -- an instance takes a new goal when it
@@ -322,10 +322,10 @@ def run_cfg5(args, fleet, dev, rank, world, dd, fence, steps, warmup):
         shard.tick()
         times.append(1e3 * (time.perf_counter() - t1))
     fence()
-    elapsed = fleet.max_over_ranks(time.perf_counter() - t0, dd, dev)
+    elapsed = fleet.max_over_ranks(time.perf_counter() - t0, dd, cdev or dev)
     ss = shard.steady_stats(reset=True)
     st = np.array([np.concatenate([ss[k]["acc"], ss[k]["events"]]) for k in ("cfg2", "cfg3", "cfg4")]).ravel()
-    allst = fleet.gather_stats(st, dd, dev)
+    allst = fleet.gather_stats(st, dd, cdev or dev)
     shard.close()
     if rank != 0:
         return None
@@ -399,11 +399,19 @@ def main():
             dist.destroy_process_group()
             raise SystemExit(3)
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RMPC_BENCH_REHEARSE=1: every rank uses GPU 0 and the collectives run over gloo on host tensors -- the multi-rank
+    # control flow of this file with real GPU work on a one-GPU box (a rehearsal of the launch, never a measurement)
+    rehearse = world > 1 and os.environ.get("RMPC_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = torch.device("cpu") if rehearse else dev     # where the (tiny) collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -424,10 +432,12 @@ def main():
     base = {"metric": METRIC, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "library_source_hash": _lib.source_hash()}
+    if rehearse:
+        base["rehearsal"] = "%d ranks share GPU 0, collectives over gloo: launch plumbing only, NOT a multi-GPU measurement" % world
 
     # ------------------------------------------------------------------ cfg5: mixed-fleet closed loop
     if cfg == "cfg5":
-        res = run_cfg5(args, fleet, dev, rank, world, dd, fence, args.steps, max(3, args.warmup))
+        res = run_cfg5(args, fleet, dev, rank, world, dd, fence, args.steps, max(3, args.warmup), cdev)
         if rank == 0:
             print(json.dumps(dict(base, **res)))
         if world > 1:
@@ -440,10 +450,10 @@ def main():
     S = max(1, min(args.streams, args.steps))
     leg = Leg(cfg, B, S, max(1, args.input_sets), dev, 1000 + 101 * rank)   # every rank owns different instances
     elapsed = timed(leg, args.steps, args.warmup, fence)
-    elapsed_max = fleet.max_over_ranks(elapsed, dd, dev)     # RCCL all-reduce(MAX)
+    elapsed_max = fleet.max_over_ranks(elapsed, dd, cdev)     # RCCL all-reduce(MAX)
     exitflag, iters, kkt = leg.stats()
     # RCCL all-gather of the solve statistics per rank (56 B): the only other collective
-    allstats = fleet.gather_stats(fleet.solve_stats(exitflag, iters, kkt), dd, dev)
+    allstats = fleet.gather_stats(fleet.solve_stats(exitflag, iters, kkt), dd, cdev)
     latency_ms, excl_wall_ms, prof = (None, None, None)
     n_excl = 0
     if not args.no_kernel_events:
@@ -470,9 +480,9 @@ def main():
         for other in ("cfg4", "cfg3"):
             lo = Leg(other, DEFAULT_BATCH[other], S, 4, dev, 2000 + 101 * rank)
             k = max(16, args.steps // 4)
-            el = fleet.max_over_ranks(timed(lo, k, 4, fence), dd, dev)
+            el = fleet.max_over_ranks(timed(lo, k, 4, fence), dd, cdev)
             ef, it, kk = lo.stats()
-            st = fleet.summarize(fleet.gather_stats(fleet.solve_stats(ef, it, kk), dd, dev), lo.B)
+            st = fleet.summarize(fleet.gather_stats(fleet.solve_stats(ef, it, kk), dd, cdev), lo.B)
             lat, wall, pr = lo.exclusive(4) if not args.no_kernel_events else (None, None, None)
             d2 = dict(lo.d, _cfg=other)
             legs[other] = {"workload": WORKLOADS[other], "value": lo.B * world * k / el, "unit": "solves/s", "steps": k,
