@@ -1496,12 +1496,30 @@ struct StepOut {
   size_t SS, KS;
 };
 
+#ifdef RMPC_RIC_STAMPS
+// development aid: cycles per phase of the generic recursion path, summed over the wavefronts of all launches
+__device__ long long g_rst[8];
+#define RST_DECL() long long rst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rst_t0 = __builtin_amdgcn_s_memtime()
+#define RST(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); rst_acc[i] += t_ - rst_t0; rst_t0 = t_; } while (0)
+#define RST_FLUSH() do { if (lane == 0) { for (int i_ = 0; i_ < 7; i_++) atomicAdd((unsigned long long *)&g_rst[i_], (unsigned long long)rst_acc[i_]); atomicAdd((unsigned long long *)&g_rst[7], 1ull); } } while (0)
+#else
+#define RST_DECL()
+#define RST(i)
+#define RST_FLUSH()
+#endif
 template <class C, int LPI>
 struct RicLds {
   static constexpr int NX = C::NX, NV = C::NV, NW = C::NW;
   static constexpr int NP2 = NX * (NX + 1) / 2;
   static constexpr int KPW = NW * NX + NW + NP2 + NX + NX;
-  static constexpr int LDSW = KPW + NX * NX + NX * NV + NV * NV + NV + NX * NV + NX + NX + NW + C::RS;   // doubles per instance
+  // The arms (one wavefront per instance, pass kernels): the chain model uses neither the [A|B] area nor T, and what
+  // that saves holds gain images: IMG_SLOTS stages' images stay in LDS between the backward and the forward pass
+  // instead of going through the gain record in global memory (budget: a quarter of the CU's 160 KB per wavefront).
+  static constexpr bool LIMG = (C::ROBOT == RMPC_ROBOT_CHAIN) && LPI == 64 && NX > 8;
+  static constexpr int ABW = LIMG ? 0 : NX * NV;    // [A|B]
+  static constexpr int TW = LIMG ? 64 : NX * NV;    // T (chains: only the idle lanes' words)
+  static constexpr int LDSW = KPW + NX * NX + ABW + NV * NV + NV + TW + NX + NX + NW + C::RS;   // doubles per instance
+  static constexpr int IMG_SLOTS = LIMG ? (40960 / 8 - LDSW) / KPW : 0;
 };
 
 // Block-tridiagonal Riccati recursion of one instance, LPI lanes.  img: the instance's LDS row (RicLds::LDSW
@@ -1523,8 +1541,10 @@ struct FusedSlots {
 template <class C, int LPI, bool SLOTS = false, class RP = gdouble, bool OWNER = false>
 __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, const double mu, const bool usec, const int lane,
                                                   ldouble *const img, const RP *const rb, gdouble *const kpb,
-                                                  const int kps, const StepOut<RP> so, ldouble *const slots = nullptr) {
+                                                  const int kps, const StepOut<RP> so, ldouble *const slots = nullptr,
+                                                  ldouble *const limg = nullptr) {
   // SLOTS: rb == slots (records), gains go to the slots as well (kpb unused)
+  // limg (RicLds::LIMG): RicLds::IMG_SLOTS gain images of KPW doubles in LDS, stages 1 .. IMG_SLOTS
   constexpr int GS = FusedSlots<C>::GS;
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NV = C::NV, NW = C::NW;
   constexpr bool DD = (C::ROBOT == RMPC_ROBOT_DIFFDRIVE);
@@ -1535,9 +1555,11 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
   constexpr int NP2 = NX * (NX + 1) / 2;
   constexpr int KPW = NW * NX + NW + NP2 + NX + NX;
   constexpr int KPL = (KPW + LPI - 1) / LPI;
+  constexpr bool LIMG = !SLOTS && RicLds<C, LPI>::LIMG;
+  constexpr int LCAP = LIMG ? RicLds<C, LPI>::IMG_SLOTS : 0;   // stages 1 .. LCAP keep their image in LDS (limg)
   ldouble *const sK = img, *const skf = sK + NW * NX, *const sPt = skf + NW, *const sp = sPt + NP2,
-               *const src = sp + NX, *const sP = img + KPW, *const sAB = sP + NX * NX, *const sQ = sAB + NX * NV,
-               *const sq = sQ + NV * NV, *const sT = sq + NV, *const sPc = sT + NX * NV, *const sdx = sPc + NX,
+               *const src = sp + NX, *const sP = img + KPW, *const sAB = sP + NX * NX, *const sQ = sAB + RicLds<C, LPI>::ABW,
+               *const sq = sQ + NV * NV, *const sT = sq + NV, *const sPc = sT + RicLds<C, LPI>::TW, *const sdx = sPc + NX,
                *const sdw = sdx + NX, *const srec = sdw + NW;   // srec: the stage record as fetched
   auto tri = [](int i, int j) __attribute__((always_inline)) {   // index of (i, j) in the packed upper triangle
     const int lo = i < j ? i : j, hi = i < j ? j : i;
@@ -2067,7 +2089,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
   }
   // ---- generic path (pass kernels; fused kernel of models without a path of their own): per-lane constants ----------
   // idle lanes store to a word of the unused T area (several lanes may share one: the value is never read)
-  ldouble *const gdummy = sT + lane % (NX * NV);
+  ldouble *const gdummy = sT + lane % RicLds<C, LPI>::TW;
   ldouble *gsrdst[RPL];
 #pragma unroll
   for (int u = 0; u < RPL; u++) gsrdst[u] = lane + LPI * u < C::RS ? srec + lane + LPI * u : gdummy;
@@ -2104,6 +2126,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
   ldouble *const gkdst = lane <= NX ? (lane < NX ? sK + lane : skf) : gdummy;
   const int gkstr = lane < NX ? NX : (lane == NX ? 1 : 0);
   if constexpr (!FAST && !DDFAST) fetch_stage(N - 1);
+  RST_DECL();
   for (int k = (FAST || DDFAST) ? -1 : N - 1; k >= 0; k--) {
     // -- the image of stage k+1 is complete: it leaves for the gain record (read now, stored after the
     //    barrier); the stage record goes to LDS, the request for the next one leaves ----------------
@@ -2117,6 +2140,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     for (int u = 0; u < RPL; u++) *gsrdst[u] = recv[u];
     if (k > 0) fetch_stage(k - 1);  // travels while this stage is computed
     WSYNC();
+    RST(0);
     if (k < N - 1) {
       if constexpr (SLOTS) {
         ldouble *const kp1 = slots + (size_t)(k + 1) * GS;
@@ -2125,6 +2149,10 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
           const int e = lane + LPI * u;
           if (e < KPW) kp1[e] = kpv[u];
         }
+      } else if (LIMG && k + 1 <= LCAP) {
+        ldouble *const kl = limg + (size_t)k * KPW;   // (slot of stage k + 1)
+#pragma unroll
+        for (int u = 0; u < KPL; u++) *(lane + LPI * u < KPW ? kl + lane + LPI * u : gdummy) = kpv[u];
       } else {
         gdouble *const kp1 = kpb + (size_t)(k + 1) * kps;
 #pragma unroll
@@ -2164,6 +2192,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
         *gpcdst = pcs;     // (stage N-1: P = 0, p = 0 -- the product is not used)
       }
       WSYNC();
+      RST(1);
       {
         const double q0v = srec[C::R_Q0 + glv], q1v = srec[C::R_Q1 + glv], pc1 = sPc[giq], pc2 = sPc[NQ + giq];
         __builtin_amdgcn_sched_barrier(0);
@@ -2172,6 +2201,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
         *gsqdst = v;
       }
       WSYNC();
+      RST(2);
     } else {
       // -- fill: dense stage Hessian, gradient, defect (rc of stage N-1: finite, unused), [A|B] -------
 #pragma unroll
@@ -2267,6 +2297,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       for (int i = 0; i < NW; i++) gkdst[i * gkstr] = col[i];
     }
     WSYNC();
+    RST(3);
     // -- cost-to-go: P = sym(Qxx + Qxw K), p = qx + Qxw kff ---------------------------------------------
     if constexpr (MFMA_P) {
       // The arms, one wavefront per instance: the 14 x 7 x 15 product on the matrix cores.  M = Qxw [K | kff] is one
@@ -2354,6 +2385,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     }
     }
     // (the fill of the next stage touches sQ / sq / src only; its barrier orders the sP writes)
+    RST(4);
   }
   if (!chol_ok) return false;
 
@@ -2507,15 +2539,25 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
   // the image of stage 0 is still in LDS; later stages come back from the gain record (one request each)
   WSYNC();
   if (lane < NX) sdx[lane] = 0.0;
-  double fv[KPL];
-  auto fetch_fwd = [&](int k) __attribute__((always_inline)) {
+  // Gain images from global memory: FD stages in flight.  (One stage ahead was not enough: a stage of the rollout is
+  // ~600 cycles of work and an image takes several thousand cycles to come back from the Infinity Cache -- the gain
+  // records of a launch, 39 MB for 1024 arms, do not fit the L2 -- so that the arm's rollout was 3.4 k cycles per
+  // stage, 40 % of its recursion: tests/tools/dev_ric_stamps.py.)  The stage loop is unrolled FD times so that the
+  // buffer index is static; requests beyond the horizon are clamped, not skipped.
+  constexpr int FD = SLOTS ? 1 : 4;
+  double fvq[FD][KPL];
+  auto fetch_fwd = [&](int k, double (&fv)[KPL]) __attribute__((always_inline)) {
+    const int kk = k < N ? k : N - 1;
 #pragma unroll
     for (int u = 0; u < KPL; u++) {
       const int e = lane + LPI * u;
-      fv[u] = kpb[(size_t)k * kps + (e < KPW ? e : 0)];
+      fv[u] = kpb[(size_t)kk * kps + (e < KPW ? e : 0)];
     }
   };
-  if (!SLOTS && N > 1) fetch_fwd(1);
+  if constexpr (!SLOTS) {
+#pragma unroll
+    for (int d = 0; d < FD; d++) fetch_fwd(LCAP + 1 + d, fvq[d]);
+  }
   // (straight-line stages as in the backward pass: clamped per-lane rows, reads before the first use, idle lanes
   //  store to gdummy; the two stores of the step to global memory stay predicated)
   const bool fisw = lane < NW, fact = lane < NW + NX;
@@ -2529,13 +2571,17 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
 #pragma unroll
   for (int u = 0; u < KPL; u++) fimg[u] = lane + LPI * u < KPW ? img + lane + LPI * u : gdummy;
   const bool fisq = glr < NQ;
-  for (int k = 0; k < N; k++) {
-    // image of this stage: stage 0's is still in the work area; later ones come back from the gain record
-    // (copied into the work area), or are read where the backward pass left them (SLOTS)
-    const ldouble *const im = (SLOTS && (k > 0 || FAST)) ? slots + (size_t)k * GS : img;
-    if (!SLOTS) {
+  auto fwd_stage = [&](const int k, double (&fv)[KPL], const bool from_mem) __attribute__((always_inline)) {
+    // image of this stage: stage 0's is still in the work area; later ones are read where the backward pass left
+    // them (SLOTS; limg for stages 1 .. LCAP), or come back from the gain record (copied into the work area)
+    const ldouble *const im = (SLOTS && (k > 0 || FAST)) ? slots + (size_t)k * GS
+                              : ((LIMG && !from_mem && k > 0) ? limg + (size_t)(k - 1) * KPW : img);
+    if constexpr (!SLOTS) {
+      if (from_mem) {
 #pragma unroll
-      for (int u = 0; u < KPL; u++) *(k > 0 ? fimg[u] : gdummy) = fv[u];
+        for (int u = 0; u < KPL; u++) *fimg[u] = fv[u];
+        fetch_fwd(k + FD, fv);   // (the buffer is free again: the image of stage k + FD takes its place)
+      }
     }
     if constexpr (DD) {
       if (k < N - 1) {   // [A|B] of stage k straight from its record (diff-drive only)
@@ -2547,8 +2593,8 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
         }
       }
     }
-    if (!SLOTS && k > 0 && k < N - 1) fetch_fwd(k + 1);
     WSYNC();
+    RST(5);
     // (the defect of the stage, read before the step of the stage may overwrite it: SLOTS)
     const double rcv = im[NW * NX + NW + NP2 + NX + glr];
     // dw = kff + K dx (lanes < NW) and nu+ = p + P dx (the next NX lanes) as ONE instruction stream: both
@@ -2564,9 +2610,22 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     for (int j = 0; j < NX; j++) sacc += rowv[j] * dxv[j];
     *fdwdst = sacc;
     const double dzv = fisw ? sacc : dxi;
-    if (fact && !fisw && k >= 1) so.nunew[(size_t)fi * so.SS + (size_t)k * so.KS] = sacc;
     // dz of the stage in one request: lanes < NW hold dw (slots NX..), the next NX lanes dx (slots 0..)
-    if (fact) so.dz[(size_t)(fisw ? NX + lane : lane - NW) * so.SS + (size_t)k * so.KS] = dzv;
+    if constexpr (SLOTS) {
+      if (fact && !fisw && k >= 1) so.nunew[(size_t)fi * so.SS + (size_t)k * so.KS] = sacc;
+      if (fact) so.dz[(size_t)(fisw ? NX + lane : lane - NW) * so.SS + (size_t)k * so.KS] = dzv;
+    } else {
+      // (unconditional stores, idle lanes to the spare word of the stage's gain record: behind a predicated store the
+      //  compiler no longer knows how many requests are in flight and waits for ALL of them -- the images of the next
+      //  stages included -- before it touches the oldest)
+      RP *const sink = (RP *)(kpb + (size_t)k * kps + KPW);
+#ifdef RMPC_EXP_NOSTORE
+      if (dzv == 1.2345e300) { *sink = sacc; }
+#else
+      *((fact && !fisw && k >= 1) ? so.nunew + (size_t)fi * so.SS + (size_t)k * so.KS : sink) = sacc;
+      *(fact ? so.dz + (size_t)(fisw ? NX + lane : lane - NW) * so.SS + (size_t)k * so.KS : sink) = dzv;
+#endif
+    }
     WSYNC();
     double dxn = 0.0;
     if constexpr (!DD) {
@@ -2589,8 +2648,23 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     }
     // (all lanes have issued their reads of sdx before this store: same wavefront, program order)
     *((k < N - 1 && lane < NX) ? sdx + lane : gdummy) = dxn;
-    // (next iteration's barrier orders this write before the reads)
+    // (next stage's barrier orders this write before the reads)
+    RST(6);
+  };
+  // stage 0 and the stages whose image stayed in LDS, then the stages from the gain record: stage LCAP + 1 + d (+ FD,
+  // + 2 FD ...) waits in buffer d
+  for (int k = 0; k < N && k <= LCAP; k++) fwd_stage(k, fvq[0], false);
+  if constexpr (!SLOTS) {
+    for (int k0 = LCAP + 1; k0 < N; k0 += FD) {
+#pragma unroll
+      for (int d = 0; d < FD; d++) {
+        if (k0 + d < N) fwd_stage(k0 + d, fvq[d], true);   // (uniform branch: N and k0 are wave-uniform)
+      }
+    }
+  } else {
+    for (int k = 1; k < N; k++) fwd_stage(k, fvq[0], false);
   }
+  RST_FLUSH();
   return true;
 }
 
@@ -2635,10 +2709,14 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     r.badf += W.part[IDX(P_BAD, k, b)];
     r.gphi += first ? 0.0 : W.gphi[(size_t)k * W.Bp + b];
   }
-  r.f = wave_sum<LPI>(r.f); r.th = wave_sum<LPI>(r.th); r.lgs = wave_sum<LPI>(r.lgs); r.sumc = wave_sum<LPI>(r.sumc);
-  r.badf = wave_sum<LPI>(r.badf); r.gphi = wave_sum<LPI>(r.gphi);
-  r.rstat = wave_max<LPI>(r.rstat); r.req = wave_max<LPI>(r.req); r.rineq = wave_max<LPI>(r.rineq); r.rcomp = wave_max<LPI>(r.rcomp);
-  r.minc = wave_min<LPI>(r.minc);
+  {
+    // (all quantities through the xor tree together, step by step: 6 exchange rounds instead of 11 x 6 dependent ones;
+    //  the same trees as wave_sum / wave_max / wave_min)
+    double rs6[6] = {r.f, r.th, r.lgs, r.sumc, r.badf, r.gphi}, rm4[4] = {r.rstat, r.req, r.rineq, r.rcomp}, rn1[1] = {r.minc};
+    wave_reduce_many<LPI>(rs6, rm4, rn1);
+    r.f = rs6[0]; r.th = rs6[1]; r.lgs = rs6[2]; r.sumc = rs6[3]; r.badf = rs6[4]; r.gphi = rs6[5];
+    r.rstat = rm4[0]; r.req = rm4[1]; r.rineq = rm4[2]; r.rcomp = rm4[3]; r.minc = rn1[0];
+  }
 
   // ---- decisions: every lane computes them (identical values), lane 0 stores ---------
   const bool L0 = (lane == 0);
@@ -2650,11 +2728,15 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   if (!recurse) return;
   const double mu = s.mu;        // nothing else of the instance state stays live across the recursion
   __shared__ double lds[IPB * IPW][RicLds<C, LPI>::LDSW];
+  constexpr int IMGW = RicLds<C, LPI>::IMG_SLOTS * RicLds<C, LPI>::KPW;
+  __shared__ double limg[IMGW > 0 ? IMGW : 1];   // (the arms: gain images of the first IMG_SLOTS stages, one-wavefront blocks)
+  static_assert(IMGW == 0 || IPB * IPW == 1, "image slots: one instance per block");
   StepOut<gdouble> so;
   so.dz = (gdouble *)(W.dz + b); so.nunew = (gdouble *)(W.nunew + b); so.SS = (size_t)N * W.Bp; so.KS = (size_t)W.Bp;
   const bool chol_ok = riccati_recursion<C, LPI, false, gdouble>(M.N, M.dt, mu, usec, lane, (ldouble *)lds[wv],
                                                                  (const gdouble *)(W.R + (size_t)b * N * C::RS),
-                                                                 (gdouble *)(W.KP + (size_t)b * N * W.kps), W.kps, so);
+                                                                 (gdouble *)(W.KP + (size_t)b * N * W.kps), W.kps, so,
+                                                                 nullptr, (ldouble *)limg);
   if (L0) {
     // = inst_after_recursion on the stored words
     if (!chol_ok) {
@@ -5155,6 +5237,13 @@ int rmpc_last_passes(rmpc_handle *h) {
 }
 
 /* development aid (builds with -DRMPC_STAMPS): per-block phase cycles of the last fused launch, 8 words per block */
+#ifdef RMPC_RIC_STAMPS
+int rmpc_debug_ric_stamps(long long *out) {   // reads and clears the recursion's phase counters
+  long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rmpc::g_rst), sizeof(z)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(rmpc::g_rst), z, sizeof(z)) != hipSuccess;
+}
+#endif
 int rmpc_debug_fused_stamps(rmpc_handle *h, long long *out, int nblocks) {
   if (!h || !h->fused) return fail("no fused workspace");
   if (nblocks > fused_columns(h->max_batch)) return fail("too many blocks");
