@@ -430,6 +430,10 @@ struct Partials {
 #endif
 };
 #ifdef RMPC_STAMPS
+// development aid: cycles per section of k_sweep (pass kernels), summed over the wavefronts of all launches
+__device__ long long g_sst[8];
+#endif
+#ifdef RMPC_STAMPS
 #define SW_STAMP(i) do { long long t_ = __builtin_amdgcn_s_memtime(); out.tk[i] = t_ - sw_t0; sw_t0 = t_; } while (0)
 #else
 #define SW_STAMP(i)
@@ -1167,6 +1171,9 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
 template <class C, class V>
 __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevModel M, const DevTables *__restrict__ Tp, const Ws W,
                                                const int B, const int first, const int warm) {
+#ifdef RMPC_STAMPS
+  const long long ks_t0 = __builtin_amdgcn_s_memtime();
+#endif
   const int gid = blockIdx.x * kSweepBlock + threadIdx.x;
   const int li = gid % W.Bp;   // position in the compacted list of iterating instances
   // (Bp % 64 == 0: the stage is the same for the 64 lanes of a wavefront; as a scalar, every test on it is a scalar
@@ -1220,6 +1227,13 @@ __global__ __launch_bounds__(kSweepBlock, C::SWEEP_WPE) void k_sweep(const DevMo
   W.part[IDXL(P_SUMC)] = pt.sumc;
   W.part[IDXL(P_MINC)] = pt.minc;
   W.part[IDXL(P_BAD)] = pt.bad;
+#ifdef RMPC_STAMPS
+  if ((threadIdx.x & 63) == 0) {
+    for (int i = 0; i < 4; i++) atomicAdd((unsigned long long *)&g_sst[i], (unsigned long long)pt.tk[i]);
+    atomicAdd((unsigned long long *)&g_sst[4], (unsigned long long)(__builtin_amdgcn_s_memtime() - ks_t0));
+    atomicAdd((unsigned long long *)&g_sst[7], 1ull);
+  }
+#endif
 }
 
 // ===========================================================================
@@ -2619,12 +2633,8 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       //  compiler no longer knows how many requests are in flight and waits for ALL of them -- the images of the next
       //  stages included -- before it touches the oldest)
       RP *const sink = (RP *)(kpb + (size_t)k * kps + KPW);
-#ifdef RMPC_EXP_NOSTORE
-      if (dzv == 1.2345e300) { *sink = sacc; }
-#else
       *((fact && !fisw && k >= 1) ? so.nunew + (size_t)fi * so.SS + (size_t)k * so.KS : sink) = sacc;
       *(fact ? so.dz + (size_t)(fisw ? NX + lane : lane - NW) * so.SS + (size_t)k * so.KS : sink) = dzv;
-#endif
     }
     WSYNC();
     double dxn = 0.0;
@@ -5237,6 +5247,13 @@ int rmpc_last_passes(rmpc_handle *h) {
 }
 
 /* development aid (builds with -DRMPC_STAMPS): per-block phase cycles of the last fused launch, 8 words per block */
+#ifdef RMPC_STAMPS
+int rmpc_debug_sweep_stamps(long long *out) {   // reads and clears k_sweep's section counters
+  long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rmpc::g_sst), sizeof(z)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(rmpc::g_sst), z, sizeof(z)) != hipSuccess;
+}
+#endif
 #ifdef RMPC_RIC_STAMPS
 int rmpc_debug_ric_stamps(long long *out) {   // reads and clears the recursion's phase counters
   long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -20,7 +20,7 @@ for cfg in cfgs:
     sc = make_scenario(cfg, B=B, seed=1000)
     d = sc.desc
     N, nv = d["N"], d["nx"] + d["ns"] + d["nu"]
-    for S in (1, 2, 4):
+    for S in tuple(int(x) for x in os.environ.get("QT_STREAMS", "1,2,4").split(",")):
         solvers = [Solver(d, max_batch=B) for _ in range(S)]
         tx = torch.from_numpy(sc.xinit).to(dev); t0 = torch.from_numpy(sc.x0).to(dev); tp = torch.from_numpy(sc.params).to(dev)
         outs = [dict(z=torch.empty((B, N, nv), dtype=torch.float64, device=dev), e=torch.empty(B, dtype=torch.int32, device=dev),
