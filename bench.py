@@ -285,7 +285,8 @@ def cpu_baseline(leg, gpu_z, gpu_exit, Solver, make_scenario, local_rank):
     gpu1_ms = 1e3 * (time.perf_counter() - t) / 20
     s1.close()
     return {
-        "value": nb / el, "unit": "solves/s", "cores": nt, "kind": "port",
+        # cores: what the run could actually occupy (threads beyond the cgroup quota share its CPUs)
+        "value": nb / el, "unit": "solves/s", "cores": int(min(nt, usable)), "threads": nt, "kind": "port",
         "sample": f"{nb} instances of the same workload (input set 0), one pass, OpenMP over instances; "
                   "the reference's own CPU path (FORCES Pro) cannot run here",
         "seconds": el, "thread_scaling": rows, "single_thread_ms_per_solve": 1e3 * per_solve_1t,
