@@ -426,7 +426,7 @@ struct SweepIO {
 struct Partials {
   double f, th, logs, rstat, req, rineq, rcomp, sumc, minc, bad;
 #ifdef RMPC_STAMPS
-  long long tk[4];   // development builds: cycles of the sections of the sweep
+  long long tk[6];   // development builds: cycles of the sections of the sweep ([4], [5]: step lengths and their reduction, fused_sweep_step_call)
 #endif
 };
 #ifdef RMPC_STAMPS
@@ -3344,6 +3344,9 @@ __device__ __noinline__ RMPC_ONE_WAVE SweepStepRes fused_sweep_step_call(const F
   const FusedPtrs Pw = fused_ptrs(F, b);
   const V v{};
   double ap = 1.0, ad = 1.0, gp = 0.0;
+#ifdef RMPC_STAMPS
+  const long long ss_t0 = __builtin_amdgcn_s_memtime();
+#endif
   if (fresh && live) {
     StepIO<ldouble> io;
     io.zc = Pw.pz[cur]; io.tc = Pw.pt[cur]; io.lc = Pw.pl[cur]; io.grow = Pw.pg[cur]; io.Jq = Pw.pj[cur];
@@ -3352,11 +3355,17 @@ __device__ __noinline__ RMPC_ONE_WAVE SweepStepRes fused_sweep_step_call(const F
     io.dz = slots + DZ_OFF; io.SSd = 1; io.loffd = (unsigned)(k * GS);
     step_body<C, ldouble, V>(v, io, k, mu, ap, ad, gp);
   }
+#ifdef RMPC_STAMPS
+  const long long ss_t1 = __builtin_amdgcn_s_memtime();
+#endif
   {
     double rs1[1] = {gp}, rm0[1] = {0.0}, rn2[2] = {ap, ad};
     wave_reduce_many<kFusedStages>(rs1, rm0, rn2);
     gp = rs1[0]; ap = rn2[0]; ad = rn2[1];
   }
+#ifdef RMPC_STAMPS
+  const long long ss_t2 = __builtin_amdgcn_s_memtime();
+#endif
   SweepStepRes r;
   r.amin_p = fresh ? fmin(amin_p_in, ap) : amin_p_in;
   r.amin_d = fresh ? fmin(amin_d_in, ad) : amin_d_in;
@@ -3378,6 +3387,9 @@ __device__ __noinline__ RMPC_ONE_WAVE SweepStepRes fused_sweep_step_call(const F
     const SweepK sk = {N, dt, use_curv};
     sweep_body<C, -1, ldouble, V, FIRSTC>(sk, v, io, k, FIRSTC != 0, nostep, alpha, adual, mu, r.q);
   }
+#ifdef RMPC_STAMPS
+  r.q.tk[4] = ss_t1 - ss_t0; r.q.tk[5] = ss_t2 - ss_t1;
+#endif
   return r;
 }
 
@@ -3440,7 +3452,7 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) v
 
 #ifdef RMPC_STAMPS
   long long st_sweep = 0, st_dec = 0, st_ric = 0, st_step = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
-  long long st_sw[4] = {0, 0, 0, 0};
+  long long st_sw[6] = {0, 0, 0, 0, 0, 0}, st_sw2[2] = {0, 0};
   int st_ipass = 0;   // instance passes of this wavefront (both halves)
 #define STAMP_A() st_a = __builtin_amdgcn_s_memtime()
 #define STAMP_B(acc) do { st_b = __builtin_amdgcn_s_memtime(); acc += st_b - st_a; st_a = st_b; } while (0)
@@ -3557,7 +3569,7 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     // ---- sweep: trial point, model functions, condensing, stage partials -------------------------------
     Partials q = {0, 0, 0, 0, 0, 0, 0, 0, 1e300, 0};
 #ifdef RMPC_STAMPS
-    q.tk[0] = q.tk[1] = q.tk[2] = q.tk[3] = 0;
+    q.tk[0] = q.tk[1] = q.tk[2] = q.tk[3] = q.tk[4] = q.tk[5] = 0;
 #endif
     // Generated views with LDS records: the step lengths of a fresh step are formed inside the sweep call (MERGE2).
     // (The same reordering for the runtime tables, inline, is bit-identical too and no faster: boxer 0.48 vs 0.50 M.)
@@ -3615,6 +3627,9 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       if (first) sweep_body<C, -1, RP, V, 1>(sk, v, io, k, true, nostep, alpha, adual, s.mu, q);
       else sweep_body<C, -1, RP, V, 0>(sk, v, io, k, false, nostep, alpha, adual, s.mu, q);
     }
+#ifdef RMPC_STAMPS
+    const long long st_ret = __builtin_amdgcn_s_memtime();   // (the sweep call has returned)
+#endif
     unpark();
     if constexpr (MERGE2) {
       if (fresh) { s.amin_p = ssr.amin_p; s.amin_d = ssr.amin_d; gphi_sum = ssr.gphi; }
@@ -3627,10 +3642,14 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       r.rstat = rm4[0]; r.req = rm4[1]; r.rineq = rm4[2]; r.rcomp = rm4[3]; r.minc = rn1[0];
     }
     r.gphi = first ? 0.0 : gphi_sum;
+#ifdef RMPC_STAMPS
+    const long long st_red = __builtin_amdgcn_s_memtime();
+#endif
     GSYNC();   // trial point and records are complete before any lane reads another lane's part
     STAMP_B(st_sweep);
 #ifdef RMPC_STAMPS
-    for (int i = 0; i < 4; i++) st_sw[i] += __builtin_amdgcn_readfirstlane((int)q.tk[i]);
+    for (int i = 0; i < 6; i++) st_sw[i] += __builtin_amdgcn_readfirstlane((int)q.tk[i]);
+    st_sw2[0] += st_red - st_ret; st_sw2[1] += st_b - st_red;   // unpark + reductions; the ordering point's wait
 #endif
     // ---- decisions, then a new step when the trial was accepted --------------------------------------
     bool usec = false;
@@ -3700,7 +3719,8 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     long long *o = F.stamps + (size_t)blockIdx.x * 8;
     {
       long long *o2 = F.stamps + (size_t)(gridDim.x + blockIdx.x) * 8;   // second half of the array: sweep sections
-      for (int i = 0; i < 4; i++) o2[i] = st_sw[i];
+      for (int i = 0; i < 6; i++) o2[i] = st_sw[i];
+      o2[6] = st_sw2[0]; o2[7] = st_sw2[1];
     }
     o[0] = st_sweep; o[1] = st_dec; o[2] = st_ric; o[3] = st_step; o[4] = __builtin_amdgcn_s_memtime() - st_t0; o[5] = pass;
     o[6] = st_t0; o[7] = st_ipass;

@@ -26,7 +26,8 @@ print(f"{cfg} B={B}: wavefronts {len(st)}, passes per wavefront mean {st[:, 5].m
       f"passes per instance mean {st[:, 7].sum() / B:.1f}")
 for i, name in enumerate(["sweep", "decide", "riccati", "step"]):
     print(f"  {name:8s} {st[:, i].sum() / tot.sum() * 100:5.1f} %   cycles per pass {st[:, i].sum() / st[:, 5].sum():9.0f}")
-if sec[:, :4].sum() > 0:
-    for i, name in enumerate(["top loads + trial point", "objective, kinematics, distance rows", "single-variable rows", "dynamics, records, log"]):
+if sec[:, :6].sum() > 0:
+    for i, name in enumerate(["top loads + trial point", "objective, kinematics, distance rows", "single-variable rows", "dynamics, records, log",
+                              "step lengths (inside the sweep call)", "their reduction", "after the call: unpark + reductions", "ordering point (wait for the stores)"]):
         print(f"     sweep / {name:38s} {sec[:, i].sum() / st[:, 5].sum():9.0f}")
 print(f"  total cycles per pass {tot.sum() / st[:, 5].sum():.0f}   (s_memtime: shader clock)")

@@ -52,7 +52,12 @@ for suffix, out in (("s4", "kernel_stats"), ("s1", "kernel_stats_streams1")):
     print(open(os.path.join(pdir, f"{tag}_{cfg}_{out}.csv")).read())
 
 counters = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(go, f"prof_{tag}_{cfg}_pmc*", "**", "*counter_collection.csv"), recursive=True):
+# (gpurun merges a call's files into gpurun_out/ without removing those of earlier calls: per counter pass only the
+#  newest collection counts, or the means would mix two libraries)
+for d in sorted(glob.glob(os.path.join(go, f"prof_{tag}_{cfg}_pmc*"))):
+    if not os.path.isdir(d):
+        continue
+    f = newest(os.path.join(d, "**", "*counter_collection.csv"))
     for r in csv.DictReader(open(f)):
         if "rmpc::" in r["Kernel_Name"]:
             counters[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))

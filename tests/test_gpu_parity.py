@@ -66,6 +66,22 @@ def test_solve_matches_oracle(rt, name, B, seed):
     np.testing.assert_allclose(gpu["obj"], cpu["obj"], rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("N", [12, 17, 30])
+def test_arm_horizons_around_the_lds_image_slots(rt, N):
+    """The arm's recursion keeps the gain images of its first 16 stages in LDS between the backward and the forward
+    pass and takes the rest from the gain record, four stages ahead (riccati_recursion, RicLds::IMG_SLOTS): a horizon
+    that fits the slots entirely, one that needs a single stage from the record, and one with more record stages than
+    prefetch buffers -- each against the oracle."""
+    sc = rt["make_scenario"]("cfg4", B=24, seed=50 + N, time_horizon=N)
+    assert sc.desc["N"] == N
+    cpu = rt["Oracle"](sc.desc).solve_batch(sc.xinit, sc.x0, sc.params)
+    s = rt["Solver"](sc.desc, max_batch=24)
+    gpu = s.solve(sc.xinit, sc.x0, sc.params)
+    s.close()
+    _check_plan(gpu, cpu, sc.desc["nx"] + sc.desc["ns"])
+    np.testing.assert_allclose(gpu["obj"], cpu["obj"], rtol=1e-9, atol=1e-9)
+
+
 @pytest.mark.parametrize("name,B,kw", [
     ("cfg1", 3, {}), ("cfg2", 2048, {}), ("cfg3", 512, {}),
     # the pass kernels: the arm (its sweep keeps the q blocks, the next stage's state and the costates in LDS columns,
