@@ -3265,6 +3265,41 @@ __device__ __forceinline__ FusedPtrs fused_ptrs(const FusedWs &F, size_t b) {
   return P;
 }
 
+// The callees of the fused kernel get the pointer block's address as an ordinary (vector register) argument.  Read
+// through it as it is, the block came in by eleven vector loads and a full wait before the first useful request of
+// the phase, and picking the current / next buffers of an array pair by a run-time index sent the pairs through scratch
+// (store, wait, indexed load: a second round trip).  The address is the same in every lane: as a scalar in the constant
+// address space the block arrives by scalar loads, and the buffers are picked by selects.
+typedef const __attribute__((address_space(4))) FusedWs cFusedWs;
+__device__ __forceinline__ cFusedWs *uniform_block(const FusedWs *p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (cFusedWs *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void load_block(FusedWs &F, const FusedWs *p) {
+  static_assert(sizeof(FusedWs) % 8 == 0, "FusedWs is copied in 8-byte words");
+  const __attribute__((address_space(4))) unsigned long long *src = (const __attribute__((address_space(4))) unsigned long long *)uniform_block(p);
+  unsigned long long *dst = (unsigned long long *)&F;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(FusedWs) / 8); i++) dst[i] = src[i];
+}
+struct FusedCur {   // an instance's bases with the current / next buffers resolved
+  gdouble *zc, *zn, *tc, *tn, *lc, *ln, *nc, *nn, *gc, *gn, *jc, *jn, *pp, *pdz, *pnn, *pgf, *pwl, *pwn;
+};
+__device__ __forceinline__ FusedCur fused_cur(const FusedWs &F, const size_t b, const int cur) {
+  const FusedPtrs P = fused_ptrs(F, b);
+  const bool c1 = cur != 0;
+  FusedCur Q;
+  Q.zc = c1 ? P.pz[1] : P.pz[0]; Q.zn = c1 ? P.pz[0] : P.pz[1];
+  Q.tc = c1 ? P.pt[1] : P.pt[0]; Q.tn = c1 ? P.pt[0] : P.pt[1];
+  Q.lc = c1 ? P.pl[1] : P.pl[0]; Q.ln = c1 ? P.pl[0] : P.pl[1];
+  Q.nc = c1 ? P.pn[1] : P.pn[0]; Q.nn = c1 ? P.pn[0] : P.pn[1];
+  Q.gc = c1 ? P.pg[1] : P.pg[0]; Q.gn = c1 ? P.pg[0] : P.pg[1];
+  Q.jc = c1 ? P.pj[1] : P.pj[0]; Q.jn = c1 ? P.pj[0] : P.pj[1];
+  Q.pp = P.pp; Q.pdz = P.pdz; Q.pnn = P.pnn; Q.pgf = P.pgf; Q.pwl = P.pwl; Q.pwn = P.pwn;
+  return Q;
+}
+
 // The sweep and the step phase are real functions for the generated views only: with the runtime tables they would
 // need the model and the tables through memory instead of through the scalar registers of the kernel.  A call takes
 // a handful of scalars -- the callee derives the instance's bases from the pointer block in device memory (scalar
@@ -3279,14 +3314,14 @@ __device__ __noinline__ RMPC_ONE_WAVE Partials fused_sweep_call(const FusedWs *F
                                                   const int warm) {
   using RP = typename std::conditional<REC_LDS, ldouble, gdouble>::type;
   constexpr int GS = FusedSlots<C>::GS, DZ_OFF = FusedSlots<C>::DZ_OFF, NV = C::NV;
-  const FusedWs &F = *Fp;
+  FusedWs F;
+  load_block(F, Fp);   // (scalar loads: uniform address, constant address space)
   const size_t S = kFusedStages;
-  const int nxt = cur ^ 1;
-  const FusedPtrs Pw = fused_ptrs(F, b);
+  const FusedCur Pw = fused_cur(F, b, cur);
   SweepIO<RP> io;
-  io.zc = Pw.pz[cur]; io.tc = Pw.pt[cur]; io.lc = Pw.pl[cur]; io.nc = Pw.pn[cur];
-  io.zn = Pw.pz[nxt]; io.tn = Pw.pt[nxt]; io.ln = Pw.pl[nxt]; io.nn = Pw.pn[nxt];
-  io.pp = Pw.pp; io.gro = Pw.pg[cur]; io.jqo = Pw.pj[cur]; io.grn = Pw.pg[nxt]; io.jqn = Pw.pj[nxt];
+  io.zc = Pw.zc; io.tc = Pw.tc; io.lc = Pw.lc; io.nc = Pw.nc;
+  io.zn = Pw.zn; io.tn = Pw.tn; io.ln = Pw.ln; io.nn = Pw.nn;
+  io.pp = Pw.pp; io.gro = Pw.gc; io.jqo = Pw.jc; io.grn = Pw.gn; io.jqn = Pw.jn;
   io.gfa = Pw.pgf;
   io.SS = S; io.loff = (unsigned)k; io.kstride = 1u;
   if constexpr (REC_LDS) {
@@ -3310,11 +3345,12 @@ __device__ __noinline__ RMPC_ONE_WAVE StepRes fused_step_call(const FusedWs *Fp,
                                                 ldouble *const slots, const double mu) {
   using RP = typename std::conditional<REC_LDS, ldouble, gdouble>::type;
   constexpr int GS = FusedSlots<C>::GS, DZ_OFF = FusedSlots<C>::DZ_OFF;
-  const FusedWs &F = *Fp;
+  FusedWs F;
+  load_block(F, Fp);   // (scalar loads: uniform address, constant address space)
   const size_t S = kFusedStages;
-  const FusedPtrs Ps = fused_ptrs(F, b);
+  const FusedCur Ps = fused_cur(F, b, cur);
   StepIO<RP> io;
-  io.zc = Ps.pz[cur]; io.tc = Ps.pt[cur]; io.lc = Ps.pl[cur]; io.grow = Ps.pg[cur]; io.Jq = Ps.pj[cur];
+  io.zc = Ps.zc; io.tc = Ps.tc; io.lc = Ps.lc; io.grow = Ps.gc; io.Jq = Ps.jc;
   io.gfa = Ps.pgf;
   io.SS = S; io.loff = (unsigned)k;
   if constexpr (REC_LDS) { io.dz = slots + DZ_OFF; io.SSd = 1; io.loffd = (unsigned)(k * GS); }
@@ -3330,18 +3366,28 @@ __device__ __noinline__ RMPC_ONE_WAVE StepRes fused_step_call(const FusedWs *Fp,
 // lanes of the instance run inside), lanes without work skip the bodies.  The slacks and multipliers the step phase
 // reads are then read again by the sweep a few thousand cycles later (L2) instead of a whole recursion later (fabric),
 // and a pass is two calls: this one and the recursion (1.90-1.94 -> 1.97-2.03 M solves/s, same results).
+// What the call hands back, per instance (identical in the 32 lanes of a half: the reductions over the stages run
+// inside the call): the reduced partials of the sweep and the step lengths.  Through LDS, not by value -- an
+// aggregate of this size is returned in memory, i.e. through scratch: a store, a full wait before the return, and a
+// load plus wait in the caller, per pass.
+struct SweepStepOut { double f, th, lgs, sumc, badf, rstat, req, rineq, rcomp, minc, amin_p, amin_d, gphi;
+#ifdef RMPC_STAMPS
+  long long tk[6];
+#endif
+};
 struct SweepStepRes { Partials q; double amin_p, amin_d, gphi; };
 template <class C, class V, int FIRSTC>
-__device__ __noinline__ RMPC_ONE_WAVE SweepStepRes fused_sweep_step_call(const FusedWs *Fp, const int N, const double dt, const int use_curv,
+__device__ __noinline__ RMPC_ONE_WAVE void fused_sweep_step_call(__attribute__((address_space(3))) SweepStepOut *const out,
+                                                                 const FusedWs *Fp, const int N, const double dt, const int use_curv,
                                                            const size_t b, const int cur, const int k, ldouble *const slots,
                                                            const bool live, const bool nostep, const bool fresh, const int ls,
                                                            const double amin_p_in, const double amin_d_in, const double gphi_in,
                                                            const double mu, const int warm) {
   constexpr int GS = FusedSlots<C>::GS, DZ_OFF = FusedSlots<C>::DZ_OFF, NV = C::NV;
-  const FusedWs &F = *Fp;
+  FusedWs F;
+  load_block(F, Fp);   // (scalar loads: uniform address, constant address space)
   const size_t S = kFusedStages;
-  const int nxt = cur ^ 1;
-  const FusedPtrs Pw = fused_ptrs(F, b);
+  const FusedCur Pw = fused_cur(F, b, cur);
   const V v{};
   double ap = 1.0, ad = 1.0, gp = 0.0;
 #ifdef RMPC_STAMPS
@@ -3349,7 +3395,7 @@ __device__ __noinline__ RMPC_ONE_WAVE SweepStepRes fused_sweep_step_call(const F
 #endif
   if (fresh && live) {
     StepIO<ldouble> io;
-    io.zc = Pw.pz[cur]; io.tc = Pw.pt[cur]; io.lc = Pw.pl[cur]; io.grow = Pw.pg[cur]; io.Jq = Pw.pj[cur];
+    io.zc = Pw.zc; io.tc = Pw.tc; io.lc = Pw.lc; io.grow = Pw.gc; io.Jq = Pw.jc;
     io.gfa = Pw.pgf;
     io.SS = S; io.loff = (unsigned)k;
     io.dz = slots + DZ_OFF; io.SSd = 1; io.loffd = (unsigned)(k * GS);
@@ -3375,9 +3421,9 @@ __device__ __noinline__ RMPC_ONE_WAVE SweepStepRes fused_sweep_step_call(const F
   r.q = qn;
   if (live) {
     SweepIO<ldouble> io;
-    io.zc = Pw.pz[cur]; io.tc = Pw.pt[cur]; io.lc = Pw.pl[cur]; io.nc = Pw.pn[cur];
-    io.zn = Pw.pz[nxt]; io.tn = Pw.pt[nxt]; io.ln = Pw.pl[nxt]; io.nn = Pw.pn[nxt];
-    io.pp = Pw.pp; io.gro = Pw.pg[cur]; io.jqo = Pw.pj[cur]; io.grn = Pw.pg[nxt]; io.jqn = Pw.pj[nxt];
+    io.zc = Pw.zc; io.tc = Pw.tc; io.lc = Pw.lc; io.nc = Pw.nc;
+    io.zn = Pw.zn; io.tn = Pw.tn; io.ln = Pw.ln; io.nn = Pw.nn;
+    io.pp = Pw.pp; io.gro = Pw.gc; io.jqo = Pw.jc; io.grn = Pw.gn; io.jqn = Pw.jn;
     io.gfa = Pw.pgf;
     io.SS = S; io.loff = (unsigned)k; io.kstride = 1u;
     io.rec = slots + k * GS;
@@ -3390,15 +3436,30 @@ __device__ __noinline__ RMPC_ONE_WAVE SweepStepRes fused_sweep_step_call(const F
 #ifdef RMPC_STAMPS
   r.q.tk[4] = ss_t1 - ss_t0; r.q.tk[5] = ss_t2 - ss_t1;
 #endif
-  return r;
+  {
+    // (idle lanes and idle halves contribute the neutral elements: their sums are discarded by the caller)
+    const Partials &q = r.q;
+    double rs5[5] = {q.f, q.th, q.logs, q.sumc, q.bad}, rm4[4] = {q.rstat, q.req, q.rineq, q.rcomp}, rn1[1] = {q.minc};
+    wave_reduce_many<kFusedStages>(rs5, rm4, rn1);
+    // (every lane of the half stores the same words: no divergence, one LDS request each)
+    out->f = rs5[0]; out->th = rs5[1]; out->lgs = rs5[2]; out->sumc = rs5[3]; out->badf = rs5[4];
+    out->rstat = rm4[0]; out->req = rm4[1]; out->rineq = rm4[2]; out->rcomp = rm4[3]; out->minc = rn1[0];
+    out->amin_p = r.amin_p; out->amin_d = r.amin_d; out->gphi = r.gphi;
+#ifdef RMPC_STAMPS
+    if (k == 0) { for (int i = 0; i < 6; i++) out->tk[i] = q.tk[i]; }
+#endif
+  }
 }
 
+// (disable_tail_calls: a phase call that hands the callee nothing of the caller's stack gets the `tail` marker, and a
+//  function with a tail-marked call site is not eligible for the no-callee-saved-registers optimisation of internal
+//  functions: the sweep call then saved and restored 300 registers through scratch on every pass.)
 // (amdgpu_waves_per_eu(1, 1): __launch_bounds__' second argument only sets the MINIMUM of waves per SIMD; with the
 //  maximum open the instruction scheduler still plans the phase functions -- which inherit the attribute -- for as
 //  many waves as it can reach and keeps their register pressure down by serialising the LDS reads of a phase:
 //  load, wait, use, load, wait, use.  One wave per SIMD is what the kernel gets anyway: 38 KB of LDS.)
 template <class C, bool REC_LDS, class V>
-__global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_fused(const DevModel M, const DevTables *__restrict__ Tp, const FusedWs F, const int B,
+__global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1), disable_tail_calls)) void k_fused(const DevModel M, const DevTables *__restrict__ Tp, const FusedWs F, const int B,
                                               const double *__restrict__ xinit, const double *__restrict__ x0,
                                               const double *__restrict__ params, double *__restrict__ zout,
                                               int *__restrict__ exitflag, int *__restrict__ iters_out,
@@ -3432,6 +3493,7 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   const size_t S = kFusedStages;
   // the solver words of the two instances are parked here around the phase calls (the callees own the register file)
   __shared__ Inst sinst[IPW];
+  __shared__ SweepStepOut sres[IPW];   // what the sweep call hands back (generated views with LDS records)
   Inst s;
   const bool warm = warm_mode != 0;
   // (every lane of an instance holds the same words: its lane 0 parks them, all lanes take them back)
@@ -3575,15 +3637,14 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     // (The same reordering for the runtime tables, inline, is bit-identical too and no faster: boxer 0.48 vs 0.50 M.)
     constexpr bool MERGE2 = V::SPEC && REC_LDS;
     park();
-    SweepStepRes ssr;
     bool fresh = false;
     if constexpr (MERGE2) {
       const bool nostep = first || (s.redo != 0);
       fresh = act && !nostep && (s.newstep != 0);
       const FusedWs *const Fp = (const FusedWs *)(Tp + 1);
-      if (v1) ssr = fused_sweep_step_call<C, V, 1>(Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, act && stage, nostep, fresh, s.ls, s.amin_p, s.amin_d, gphi_sum, s.mu, warm ? 1 : 0);
-      else ssr = fused_sweep_step_call<C, V, 0>(Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, act && stage, nostep, fresh, s.ls, s.amin_p, s.amin_d, gphi_sum, s.mu, warm ? 1 : 0);
-      q = ssr.q;
+      __attribute__((address_space(3))) SweepStepOut *const so = (__attribute__((address_space(3))) SweepStepOut *)&sres[half];
+      if (v1) fused_sweep_step_call<C, V, 1>(so, Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, act && stage, nostep, fresh, s.ls, s.amin_p, s.amin_d, gphi_sum, s.mu, warm ? 1 : 0);
+      else fused_sweep_step_call<C, V, 0>(so, Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, act && stage, nostep, fresh, s.ls, s.amin_p, s.amin_d, gphi_sum, s.mu, warm ? 1 : 0);
     } else if constexpr (V::SPEC) {
       // generated view: the sweep is a call (scalars in, partials out)
       if (act && stage) {
@@ -3631,11 +3692,17 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     const long long st_ret = __builtin_amdgcn_s_memtime();   // (the sweep call has returned)
 #endif
     unpark();
-    if constexpr (MERGE2) {
-      if (fresh) { s.amin_p = ssr.amin_p; s.amin_d = ssr.amin_d; gphi_sum = ssr.gphi; }
-    }
     Reduced r;
-    {
+    if constexpr (MERGE2) {
+      // (the call has reduced over the stages and left the instance's words in LDS: unpark's fence orders the reads)
+      const SweepStepOut o = sres[half];
+      if (fresh) { s.amin_p = o.amin_p; s.amin_d = o.amin_d; gphi_sum = o.gphi; }
+      r.f = o.f; r.th = o.th; r.lgs = o.lgs; r.sumc = o.sumc; r.badf = o.badf;
+      r.rstat = o.rstat; r.req = o.req; r.rineq = o.rineq; r.rcomp = o.rcomp; r.minc = o.minc;
+#ifdef RMPC_STAMPS
+      for (int i = 0; i < 6; i++) q.tk[i] = o.tk[i];
+#endif
+    } else {
       double rs5[5] = {q.f, q.th, q.logs, q.sumc, q.bad}, rm4[4] = {q.rstat, q.req, q.rineq, q.rcomp}, rn1[1] = {q.minc};
       wave_reduce_many<LPI>(rs5, rm4, rn1);
       r.f = rs5[0]; r.th = rs5[1]; r.lgs = rs5[2]; r.sumc = rs5[3]; r.badf = rs5[4];
