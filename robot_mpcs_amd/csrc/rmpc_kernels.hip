@@ -1549,7 +1549,13 @@ struct FusedSlots {
   static constexpr int KPW = RicLds<C, 32>::KPW;
   static constexpr int DZ_OFF = C::RW + 1;
   static constexpr int NEED = (KPW > DZ_OFF + C::NV + C::NX) ? KPW : DZ_OFF + C::NV + C::NX;
-  static constexpr int GS = (NEED + 7) / 8 * 8;   // 64-byte slots: the sweep stores its record with aligned 16-byte writes
+  // 16-byte aligned slots (the sweep stores its record with aligned 16-byte writes) whose stride is NOT a multiple of
+  // the 256 bytes the 64 LDS banks span: in the sweep and the step phase lane = stage, i.e. the lanes of an instance
+  // address the same word of 32 different slots -- with a stride of 512 bytes every one of those requests was a
+  // 32-way bank conflict (SQ_LDS_BANK_CONFLICT: 20 % of the LDS cycles of the kernel)
+  // (+2 doubles: a stride of 4 banks -- 16-byte writes of 16 lanes cover the 64 banks once; A/B on one box, four
+  //  batches in flight: 2.45-2.52 -> 2.61-2.62 M solves/s)
+  static constexpr int GS = (NEED + 7) / 8 * 8 + 2;
 };
 
 template <class C, int LPI, bool SLOTS = false, class RP = gdouble, bool OWNER = false>
