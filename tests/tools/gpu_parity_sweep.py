@@ -1,11 +1,11 @@
 """Development aid: GPU vs oracle over several seeds and batch sizes (wider than the test-suite cases)."""
 import os, sys, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from robot_mpcs_amd.scenarios import make_scenario
 from robot_mpcs_amd._lib import Solver
 from oracle.oracle import Oracle
 worst = 0.0
-for name, B in [('cfg2', 1500), ('cfg3', 1100), ('cfg4', 300), ('boxer', 130), ('pointRobot', 70), ('panda', 9)]:
+for name, B in [('cfg2', 1500), ('cfg3', 1100), ('cfg4', 300), ('boxer', 130), ('pointRobot', 70), ('panda', 9), ('chain4', 100), ('chain6', 100), ('wc_panda', 60)]:
     for seed in (101, 202, 303):
         sc = make_scenario(name, B=B, seed=seed)
         cpu = Oracle(sc.desc).solve_batch(sc.xinit, sc.x0, sc.params)

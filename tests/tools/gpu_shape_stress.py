@@ -1,12 +1,12 @@
 """Development aid: GPU vs oracle over odd batch sizes and horizons (index logic of the pass kernels, the half-wave
 Riccati blocks and the survivor migration)."""
 import os, sys, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from robot_mpcs_amd.scenarios import make_scenario
 from robot_mpcs_amd._lib import Solver
 from oracle.oracle import Oracle
 bad = 0
-for name, horizons in (("cfg2", (5, 12, 30, 47)), ("cfg3", (8, 30)), ("cfg4", (6, 20))):
+for name, horizons in (("cfg2", (5, 12, 30, 47)), ("cfg3", (8, 30)), ("cfg4", (6, 17, 20, 33)), ("chain5", (10, 24)), ("chain2", (9, 31))):
     for N in horizons:
         for B in (1, 63, 65, 511, 513, 1023, 1025, 1537):
             if name != "cfg2" and B > 600:
