@@ -3211,6 +3211,7 @@ struct FusedWs {
   int *passes;                    // [0] most passes any instance of the last launch needed, [1] the launch's queue counter
   int *lastp;                     // [B] passes of every instance in the last launch
   int *order;                     // [B] launch order of the next warm-started launch: instances by lastp, longest first
+  int *ckey;                      // [B] launch-order keys of a cold launch (k_difficulty)
   long long *stamps;              // [blocks][8] cycles per phase (builds with -DRMPC_STAMPS only; development aid)
   int rs, kps, nv, m, nx, npar, nhs, njqs;
 };
@@ -3801,16 +3802,20 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1), di
 #endif
 }
 
-#if RMPC_TU_MAIN
-// Launch order of a warm-started fused launch: the instances sorted by the passes of their previous solve, longest
-// first (counting sort, one block; the order inside a bucket is whatever the atomics give -- it changes which
-// instances share a wavefront, never what an instance computes).
-__global__ __launch_bounds__(1024) void k_order(const int *__restrict__ key, int *__restrict__ order, int B) {
+// Launch order of a fused launch: the instances sorted by a key (the passes of their previous solve for a warm start,
+// k_difficulty's estimate for a cold one), largest first (counting sort, one block; the order inside a bucket is
+// whatever the atomics give -- it changes which instances share a wavefront, never what an instance computes).
+// (static: every translation unit of the build launches it from its variants' launchers and keeps its own copy)
+// (NT = 64 for the order of a cold launch, which runs IN FRONT of the fused launch: with other handles' fused launches
+//  on the chip every SIMD is held by one long-lived 512-register wavefront, and a block of several wavefronts would
+//  wait until a whole compute unit has drained; a single wavefront takes the first SIMD that frees)
+template <int NT>
+static __global__ __launch_bounds__(NT) void k_order_t(const int *__restrict__ key, int *__restrict__ order, int B) {
   __shared__ int cnt[256];
   const int tid = threadIdx.x;
-  if (tid < 256) cnt[tid] = 0;
+  for (int i = tid; i < 256; i += NT) cnt[i] = 0;
   __syncthreads();
-  for (int b = tid; b < B; b += 1024) {
+  for (int b = tid; b < B; b += NT) {
     int kq = key[b];
     kq = kq < 0 ? 0 : (kq > 255 ? 255 : kq);
     atomicAdd(&cnt[255 - kq], 1);
@@ -3821,14 +3826,12 @@ __global__ __launch_bounds__(1024) void k_order(const int *__restrict__ key, int
     for (int i = 0; i < 256; i++) { const int c = cnt[i]; cnt[i] = run; run += c; }
   }
   __syncthreads();
-  for (int b = tid; b < B; b += 1024) {
+  for (int b = tid; b < B; b += NT) {
     int kq = key[b];
     kq = kq < 0 ? 0 : (kq > 255 ? 255 : kq);
     order[atomicAdd(&cnt[255 - kq], 1)] = b;
   }
 }
-
-#endif  // RMPC_TU_MAIN
 
 // ===========================================================================
 // Scene packing and closed-loop advance: device
@@ -4014,6 +4017,58 @@ __global__ __launch_bounds__(256) void k_retarget(const DevModel M, const DevTab
   dwell[b] = dw;
 }
 
+// Launch order of a COLD fused launch that is larger than the chip (more instances than half-wavefronts: the rest wait
+// in the queue).  A lone launch lasts as long as its slowest instance needs from the moment it is dequeued, and the
+// slow ones of a cold batch are mostly those that start close to a constraint boundary (the interior-point method's
+// first steps are cut by the fraction to the boundary): on the BASELINE scenarios 37-40 of the 40 slowest of 4096
+// point robots are in the closer half.  One lane per instance evaluates the distance rows (obstacle, plane, self
+// collision) of the start state with the parameters of the second stage and hands k_order a key, closest first --
+// longest-processing-time-first scheduling with an estimate instead of the previous solve's count.  What an instance
+// computes does not depend on its place in the queue (test_launch_order_...).
+template <class C>
+__global__ __launch_bounds__(64) void k_difficulty(const DevModel M, const DevTables *__restrict__ Tp, const int B,
+                                                    const double *__restrict__ xinit, const double *__restrict__ params,
+                                                    int *__restrict__ key) {
+  constexpr int NQ = C::NQ, NX = C::NX;
+  const int b = blockIdx.x * 64 + threadIdx.x;   // (one-wavefront blocks: see k_order_t)
+  if (b >= B) return;
+  const RtView v(M, *Tp);
+  const double *const P = params + ((size_t)b * M.N + (M.N > 1 ? 1 : 0)) * M.npar;
+  double q[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; j++) q[j] = xinit[(size_t)b * NX + j];
+  Kin<C> kin;
+  kin.compute(v, q);
+  const double rbody = (v.off_r_body() >= 0) ? P[v.off_r_body()] : 0.0;
+  double dmin = 1e30;
+  for_range<0, kMaxSlots>([&](auto slc) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slc)::value;
+    if (SL < v.nslots()) {
+      Vec3 J[NQ];
+      const Vec3 Pt = kin.template point<SL>(v, J);
+      for (int r = v.slot_row_begin(SL); r < v.slot_row_begin(SL + 1); r++) {
+        const int kind = v.fk_kind(r), ob = v.fk_obst(r);
+        double h;
+        if (kind == ROW_RADIAL) {
+          const double *o = P + v.off_obst() + 4 * ob;
+          const Vec3 dv = {Pt.x - o[0], Pt.y - o[1], Pt.z - o[2]};
+          h = sqrt(dot(dv, dv)) - o[3] - rbody;
+        } else if (kind == ROW_LINEAR) {
+          const double *o = P + v.off_lin() + 4 * ob;
+          const Vec3 av = {o[0], o[1], o[2]};
+          h = fabs(dot(av, Pt) + o[3]) / sqrt(dot(av, av)) - rbody;
+        } else {
+          h = sqrt(dot(Pt, Pt)) - 2.0 * rbody;
+        }
+        dmin = fmin(dmin, h);
+      }
+    }
+  });
+  // 256 classes of 2 cm, the closest (and every infeasible start) in the class that is dequeued first
+  const double c = dmin > 0.0 ? dmin * 50.0 : 0.0;
+  key[b] = 255 - (c < 255.0 ? (int)c : 255);
+}
+
 #if RMPC_TU_MAIN
 // ===========================================================================
 // Free-space decomposition: lidar point cloud -> at most K half-planes
@@ -4135,7 +4190,7 @@ struct rmpc_handle {
   double prof_bytes[RMPC_NUM_KERNELS] = {0};     // accumulated algorithmic bytes of the profiled launches
   std::vector<int> h_hist;
   // debugging switches, read once at rmpc_create (never set by the product code)
-  bool env_no_migrate = false, env_dump_hist = false, env_no_order = false;
+  bool env_no_migrate = false, env_dump_hist = false, env_no_order = false, env_no_cold_order = false;
 };
 
 // ---- per-variant launchers -----------------------------------------------------------------------------------------
@@ -4196,10 +4251,19 @@ int launch_fused_t(rmpc_handle *h, int B, const double *d_xinit, const double *d
   const int warm = (h->warm_mode && h->have_duals) ? 1 : 0;
   if (h->F.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
   // closed loop: the previous solve of this batch tells which instances take long (k_fused: launch order)
-  const int use_order = (warm && !h->env_no_order) ? 1 : 0;
+  int use_order = (warm && !h->env_no_order) ? 1 : 0;
   // the grid is the chip (one wavefront per SIMD: __launch_bounds__(64, 1)), the batch is a queue its halves drain
   const int pairs = (B + 1) / 2;
   const int grid = pairs < h->fused_grid ? pairs : h->fused_grid;
+  // cold launch with a queue behind the grid: the instances closest to a constraint boundary first (k_difficulty)
+  // (holonomic chains only: measured on the BASELINE batches, one launch alone 3.05 -> 2.59 ms for the point robots,
+  //  14.7 -> 15.0 ms for the boxers, whose slow instances are slow for another reason -- the Gauss-Newton blocks of the
+  //  unicycle converge linearly -- and gain nothing from the two little kernels in front of the launch)
+  if (C::ROBOT == RMPC_ROBOT_CHAIN && !warm && !h->env_no_order && !h->env_no_cold_order && d_params && pairs > grid) {
+    hipLaunchKernelGGL((k_difficulty<C>), dim3((B + 63) / 64), dim3(64), 0, st, h->M, h->d_T, B, d_xinit, d_params, h->F.ckey);
+    hipLaunchKernelGGL(k_order_t<64>, dim3(1), dim3(64), 0, st, (const int *)h->F.ckey, h->F.order, B);
+    use_order = 1;
+  }
   hipLaunchKernelGGL((k_fused<C, C::FUSED_REC_LDS, V>), dim3(grid), dim3(64), 0, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
                      d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm, use_order);
   return 0;
@@ -4813,6 +4877,7 @@ static size_t carve_fused(const DevModel &M, int Bcap, void *base, FusedWs &F) {
   F.passes = c.take<int>(64);
   F.lastp = c.take<int>(Bcap);
   F.order = c.take<int>(Bcap);
+  F.ckey = c.take<int>(Bcap);
   F.stamps = c.take<long long>((size_t)Bcap * 8);
   return (c.off + 255) & ~(size_t)255;
 }
@@ -4852,7 +4917,7 @@ static int launch_fused(rmpc_handle *h, int B, const double *d_xinit, const doub
     // the order of the NEXT warm-started launch, right behind this one (in front of it the little kernel would wait
     // for a free SIMD whenever another handle's fused launch fills the chip: 130 us in the fleet loop)
     if (h->warm_mode && !h->env_no_order)
-      hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const int *)h->F.lastp, h->F.order, B);
+      hipLaunchKernelGGL(k_order_t<1024>, dim3(1), dim3(1024), 0, st, (const int *)h->F.lastp, h->F.order, B);
     return 0;
   }
   if (rc != -2) return rc;
@@ -5093,6 +5158,7 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   if (const char *rl = getenv("RMPC_RIC_LANE")) h->ric_lane = atoi(rl);   // (development switch)
   h->env_no_migrate = getenv("RMPC_NO_MIGRATE") != nullptr;
   h->env_no_order = getenv("RMPC_NO_ORDER") != nullptr;   // (development switch: fused launches in index order)
+  h->env_no_cold_order = getenv("RMPC_NO_COLD_ORDER") != nullptr;   // (development switch: cold fused launches in index order)
   h->env_dump_hist = getenv("RMPC_DUMP_HIST") != nullptr;
   *out = h;
   return 0;

@@ -242,3 +242,19 @@ def test_launch_order_of_warm_fused_launches_changes_no_result(rt, name, B, monk
         x0 = np.where(ok[:, None, None], np.concatenate([z[:, 1:], z[:, -1:]], axis=1), x0)
         x = np.where(ok[:, None], z[:, 1, :nx], x)
     a.close(); b.close()
+
+
+def test_launch_order_of_cold_fused_launches_changes_no_result(rt, monkeypatch):
+    """A cold fused launch that is larger than the chip takes the instances closest to a constraint boundary first
+    (k_difficulty + k_order_t<64>: an estimate of who takes long; holonomic chains); RMPC_NO_COLD_ORDER=1 keeps the
+    index order.  The place in the queue must not change a bit of what an instance computes."""
+    B = 4096            # (more than two instances per wavefront of the chip: there is a queue to order)
+    sc = rt["make_scenario"]("cfg2", B=B, seed=11)
+    monkeypatch.delenv("RMPC_NO_COLD_ORDER", raising=False)
+    a = rt["Solver"](sc.desc, max_batch=B)
+    monkeypatch.setenv("RMPC_NO_COLD_ORDER", "1")     # (read once, at rmpc_create)
+    b = rt["Solver"](sc.desc, max_batch=B)
+    ra = a.solve(sc.xinit, sc.x0, sc.params); rb = b.solve(sc.xinit, sc.x0, sc.params)
+    a.close(); b.close()
+    for key in ("z", "exitflag", "iters", "obj", "kkt"):
+        assert np.array_equal(ra[key], rb[key]), key
