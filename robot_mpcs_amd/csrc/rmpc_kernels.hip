@@ -43,21 +43,22 @@
 
 // ---- kernel variants and translation units ---------------------------------------------------------------------
 // One kernel variant per robot family and size: X(id, robot kind, n, ns).  ids 0 .. 5 are the shipped configurations
-// (point robot, panda, boxer, each without / with the slack variable); 6 .. 9 further holonomic chains (mpcBase.py:52-55:
+// (point robot, panda, boxer, each without / with the slack variable); 6 .. 10 further holonomic chains (mpcBase.py:52-55:
 // n = fk.n() of whatever URDF chain the YAML names), the sizes the test suite can build from the shipped URDFs
-// (tests: chain2, chain4, chain5, chain6).  Another size is one more line here, one more #if block below
+// (tests: chain2, chain4, chain5, chain6), and n = 8 = RMPC_MAX_JOINTS (test: chain8, the panda's chain with one more
+// revolute joint).  Another size is one more line here, one more #if block below
 // (instantiation list) and one more bit in __graft_entry__.TU_MASKS.
 #define RMPC_VARIANTS(X)                                                                                                  \
   X(0, RMPC_ROBOT_CHAIN, 3, 0) X(1, RMPC_ROBOT_CHAIN, 3, 1) X(2, RMPC_ROBOT_CHAIN, 7, 0) X(3, RMPC_ROBOT_CHAIN, 7, 1)    \
   X(4, RMPC_ROBOT_DIFFDRIVE, 3, 0) X(5, RMPC_ROBOT_DIFFDRIVE, 3, 1) X(6, RMPC_ROBOT_CHAIN, 2, 0) X(7, RMPC_ROBOT_CHAIN, 4, 0) \
-  X(8, RMPC_ROBOT_CHAIN, 5, 0) X(9, RMPC_ROBOT_CHAIN, 6, 0)
+  X(8, RMPC_ROBOT_CHAIN, 5, 0) X(9, RMPC_ROBOT_CHAIN, 6, 0) X(10, RMPC_ROBOT_CHAIN, 8, 0)
 // The library is built from this one source compiled several times in parallel (__graft_entry__.build: one translation
 // unit per group of variants, minutes of compile time otherwise): RMPC_DEV_VARIANTS is the bit mask of the variants whose
 // kernels THIS translation unit instantiates, RMPC_ALL_VARIANTS the mask of the variants the library holds (what the
 // dispatch offers), RMPC_TU_MAIN says whether this unit carries the host side and the variant-independent kernels.
 // A plain one-file build (hipcc rmpc_kernels.hip) has all three at their defaults: everything in one unit.
 #ifndef RMPC_DEV_VARIANTS
-#define RMPC_DEV_VARIANTS 0x3ff
+#define RMPC_DEV_VARIANTS 0x7ff
 #endif
 #ifndef RMPC_ALL_VARIANTS
 #define RMPC_ALL_VARIANTS RMPC_DEV_VARIANTS
@@ -4387,6 +4388,12 @@ static_assert(variant_id(RMPC_ROBOT_CHAIN, 6, 0) == 9, "instantiation list out o
 RMPC_INST(template, RMPC_ROBOT_CHAIN, 6, 0)
 #elif (RMPC_ALL_VARIANTS >> 9) & 1
 RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 6, 0)
+#endif
+static_assert(variant_id(RMPC_ROBOT_CHAIN, 8, 0) == 10, "instantiation list out of step with RMPC_VARIANTS");
+#if (RMPC_DEV_VARIANTS >> 10) & 1
+RMPC_INST(template, RMPC_ROBOT_CHAIN, 8, 0)
+#elif (RMPC_ALL_VARIANTS >> 10) & 1
+RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 8, 0)
 #endif
 #undef RMPC_INST
 #undef RMPC_INST_F

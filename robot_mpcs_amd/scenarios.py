@@ -44,6 +44,7 @@ CONFIG_FILES = {
     "chain5": "t_chain5Mpc.yaml",
     "chain4": "t_chain4Mpc.yaml",
     "chain6": "t_chain6Mpc.yaml",
+    "chain8": "t_chain8Mpc.yaml",
 }
 DEFAULT_BATCH = {"cfg1": 1, "cfg2": 4096, "cfg3": 4096, "cfg4": 1024}
 
@@ -104,6 +105,8 @@ PANDA_LIMITS_U = np.array([
     [-1.0, -1.0, -15.0, -15.0, -7.5, -10.0, -12.5],
     [1.0, 1.0, 15.0, 15.0, 7.5, 10.0, 12.5],
 ])
+# (the extra joint of the test asset panda_tool8.urdf, configuration chain8: position and input limits)
+TOOL8_LIMITS = np.array([[-2.0, -12.5], [2.0, 12.5]])
 
 
 def make_scenario(name: str, B: int | None = None, seed: int = 0, **mpc_overrides) -> Scenario:
@@ -207,8 +210,10 @@ def make_scenario(name: str, B: int | None = None, seed: int = 0, **mpc_override
     elif robot == "panda":
         r_body = 0.14
         nj = model._n   # (7 for the panda; the test configuration chain5 cuts the chain after joint 5)
-        lim, limu = PANDA_LIMITS[:, :nj], PANDA_LIMITS_U[:, :nj]
-        q0 = np.median(lim, axis=0)[None, :] + (rng.uniform(-0.3, 0.3, size=(B, 7))[:, :nj] if B > 1 else 0.0)
+        lim8 = np.concatenate([PANDA_LIMITS, TOOL8_LIMITS[:, 0:1]], axis=1)
+        limu8 = np.concatenate([PANDA_LIMITS_U, TOOL8_LIMITS[:, 1:2]], axis=1)
+        lim, limu = lim8[:, :nj], limu8[:, :nj]
+        q0 = np.median(lim, axis=0)[None, :] + (rng.uniform(-0.3, 0.3, size=(B, max(7, nj)))[:, :nj] if B > 1 else 0.0)
         q0 = np.clip(q0, lim[0] + 0.05, lim[1] - 0.05)
         xinit[:, 0:nj] = q0
         jit = (lambda s, sz: rng.uniform(-s, s, size=sz)) if B > 1 else (lambda s, sz: np.zeros(sz))

@@ -53,8 +53,10 @@ def _check_plan(gpu, cpu, nxs, tol_stat=1e-6):
     # as "first row of a module", Linear rows, self-collision rows)
     ("wc_point", 96, 31), ("wc_boxer", 96, 32), ("wc_boxer_slack", 96, 33), ("wc_panda", 40, 34),
     # kernel variants beyond the three shipped robots (mpcBase.py:52-55: n = fk.n() of any URDF chain): a 2-joint
-    # gantry (fused kernel) and 4 / 5 / 6-joint arms (pass kernels; n = 5, 6 with the cost-to-go update on the matrix cores)
+    # gantry (fused kernel) and 4 / 5 / 6 / 8-joint arms (pass kernels; n = 5, 6 with the cost-to-go update on the matrix cores)
     ("chain2", 96, 41), ("chain4", 48, 42), ("chain5", 48, 43), ("chain6", 48, 44),
+    # n = 8 = RMPC_MAX_JOINTS: the panda's chain with one more revolute joint (test asset panda_tool8.urdf)
+    ("chain8", 32, 45),
 ])
 def test_solve_matches_oracle(rt, name, B, seed):
     sc = rt["make_scenario"](name, B=B, seed=seed)
@@ -88,7 +90,7 @@ def test_arm_horizons_around_the_lds_image_slots(rt, N):
     # its recursion the stage matrices; 420 B of scratch per lane), a weighted arm, and horizons beyond the fused
     # kernel's 32 stages (point robot and boxer through k_sweep / k_riccati / k_step, with survivor migration)
     ("cfg4", 256, {}), ("wc_panda", 64, {}), ("cfg2", 1536, {"time_horizon": 40}), ("cfg3", 192, {"time_horizon": 36}),
-    ("chain2", 64, {}), ("chain5", 64, {}),
+    ("chain2", 64, {}), ("chain5", 64, {}), ("chain8", 24, {}),
 ])
 def test_solve_does_not_depend_on_stale_lds(rt, name, B, kw):
     """Every word a kernel reads from LDS, scratch or the handle's workspace must have been written by the same solve:
