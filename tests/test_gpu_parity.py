@@ -68,6 +68,20 @@ def test_solve_matches_oracle(rt, name, B, seed):
     np.testing.assert_allclose(gpu["obj"], cpu["obj"], rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("name,B,seed", [("cfg2", 300, 61), ("wc_point", 200, 62), ("chain2", 200, 63), ("cfg3", 200, 64)])
+def test_queue_and_cold_order_on_a_tiny_grid(rt, name, B, seed, monkeypatch):
+    """RMPC_FUSED_GRID=4: eight half-wavefronts drain a queue of hundreds of instances, and a cold launch of the
+    chains orders that queue by k_difficulty -- the refill, the per-instance pass counters, the mixed first / later
+    sweeps of a wavefront's two halves and the launch order, exercised at test sizes, against the oracle."""
+    monkeypatch.setenv("RMPC_FUSED_GRID", "4")       # (read once, at rmpc_create)
+    sc = rt["make_scenario"](name, B=B, seed=seed)
+    cpu = rt["Oracle"](sc.desc).solve_batch(sc.xinit, sc.x0, sc.params)
+    s = rt["Solver"](sc.desc, max_batch=B)
+    gpu = s.solve(sc.xinit, sc.x0, sc.params)
+    s.close()
+    _check_plan(gpu, cpu, sc.desc["nx"] + sc.desc["ns"])
+
+
 @pytest.mark.parametrize("N", [12, 17, 30])
 def test_arm_horizons_around_the_lds_image_slots(rt, N):
     """The arm's recursion keeps the gain images of its first 16 stages in LDS between the backward and the forward
