@@ -70,9 +70,11 @@ def parse():
     ap.add_argument("--no-full-chip", action="store_true", help="skip the one-launch-fills-the-chip leg (profiles: keeps the kernel average to launches of one batch)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the exclusive per-kernel leg")
     ap.add_argument("--max-iter", type=int, default=40, help="cfg5 only: iteration cap of the real-time loop (what ends a slow solve is the pass budget)")
-    ap.add_argument("--pass-budget", type=int, default=24, help="cfg5: real-time deadline of a solve in passes (horizon evaluations; 0 = none).  "
+    ap.add_argument("--pass-budget", type=int, default=32, help="cfg5: real-time deadline of a solve in passes (horizon evaluations; 0 = none).  "
                     "What it cuts are line searches that backtrack and instances that need more than a couple of dozen iterations")
-    ap.add_argument("--pass-budget-boxer", type=int, default=48, help="cfg5: the boxers' deadline if it differs (0 = --pass-budget)")
+    ap.add_argument("--pass-budget-arm", type=int, default=16, help="cfg5: the arms' deadline if it differs (0 = --pass-budget).  The control step of "
+                    "the shard hangs on this one: a pass of the arms is four kernel launches that queue behind the other fleets' fused launches")
+    ap.add_argument("--pass-budget-boxer", type=int, default=56, help="cfg5: the boxers' deadline if it differs (0 = --pass-budget)")
     ap.add_argument("--acc-iters", type=int, default=3, help="cfg5: acceptable-termination window of the real-time loop (consecutive stagnant feasible iterations; the configs' default is 8)")
     ap.add_argument("--max-dwell", type=int, default=150, help="cfg5: control steps after which an instance takes its next goal even if it has not arrived")
     ap.add_argument("--mu-regoal-boxer", type=float, default=-1.0, help="cfg5 (development): barrier parameter a boxer's first solve after a goal hand-over restarts from (default: the fleet's)")
@@ -310,7 +312,7 @@ def run_cfg5(args, fleet, dev, rank, world, dd, fence, steps, warmup, cdev=None)
     shard = fleet.MixedFleetShard(counts, dev, seed=7 + rank, previous_plan=True, warm_duals=True,
                                   options={"max_iter": args.max_iter, "acc_iters": args.acc_iters},
                                   pass_budget={"cfg2": args.pass_budget, "cfg3": args.pass_budget_boxer or args.pass_budget,
-                                               "cfg4": args.pass_budget}, steady=True, max_dwell=args.max_dwell,
+                                               "cfg4": args.pass_budget_arm or args.pass_budget}, steady=True, max_dwell=args.max_dwell,
                                   mu_regoal=({"cfg3": args.mu_regoal_boxer} if args.mu_regoal_boxer >= 0 else None))
     for _ in range(warmup):
         shard.tick()
@@ -350,6 +352,7 @@ def run_cfg5(args, fleet, dev, rank, world, dd, fence, steps, warmup, cdev=None)
                 config={"workload": WORKLOADS["cfg5"], "instances_per_gpu": 8192, "max_iter": args.max_iter,
                         "acc_iters": args.acc_iters, "pass_budget": args.pass_budget,
                         "pass_budget_boxer": args.pass_budget_boxer or args.pass_budget,
+                        "pass_budget_arm": args.pass_budget_arm or args.pass_budget,
                         "loop": "steady: new goal on arrival (or after %d control steps), start state after a failed solve; no episodes" % args.max_dwell,
                         "warm_start": "shifted plan + multipliers (rmpc_set_warm_start)",
                         "parallelism": f"{world} x per-robot-type blocks (fleet.partition_mixed), no data-path collective"},

@@ -175,7 +175,7 @@ def test_mixed_fleet_steady_loop_full_shard(rt):
     counts = {"cfg2": 4096, "cfg3": 3072, "cfg4": 1024}
     dev = torch.device("cuda:0")
     shard = fleet.MixedFleetShard(counts, dev, seed=7, previous_plan=True, warm_duals=True,
-                                  options={"max_iter": 40, "acc_iters": 3}, pass_budget={"cfg2": 24, "cfg3": 48, "cfg4": 24},
+                                  options={"max_iter": 40, "acc_iters": 3}, pass_budget={"cfg2": 32, "cfg3": 56, "cfg4": 16},
                                   steady=True, max_dwell=150)
     assert shard.instances == 8192
     for _ in range(10):
