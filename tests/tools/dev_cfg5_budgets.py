@@ -14,8 +14,8 @@ from robot_mpcs_amd import fleet  # noqa: E402
 
 counts = {"cfg2": 4096, "cfg3": 3072, "cfg4": 1024}
 dev = torch.device("cuda:0")
-for pb in ({"cfg2": 32, "cfg3": 48, "cfg4": 16}, {"cfg2": 32, "cfg3": 56, "cfg4": 16}, {"cfg2": 28, "cfg3": 48, "cfg4": 14}, {"cfg2": 36, "cfg3": 56, "cfg4": 18},
-           {"cfg2": 40, "cfg3": 64, "cfg4": 16}):
+for pb in ({"cfg2": 32, "cfg3": 56, "cfg4": 16}, {"cfg2": 32, "cfg3": 56, "cfg4": 20},
+           {"cfg2": 32, "cfg3": 56, "cfg4": 24}):
     shard = fleet.MixedFleetShard(counts, dev, seed=7, previous_plan=True, warm_duals=True, options={"max_iter": 40, "acc_iters": 3},
                                   pass_budget=pb, steady=True, max_dwell=150)
     for _ in range(10):
