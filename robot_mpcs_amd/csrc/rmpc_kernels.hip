@@ -1533,9 +1533,33 @@ struct RicLds {
   static constexpr bool LIMG = (C::ROBOT == RMPC_ROBOT_CHAIN) && LPI == 64 && NX > 8;
   static constexpr int ABW = LIMG ? 0 : NX * NV;    // [A|B]
   static constexpr int TW = LIMG ? 64 : NX * NV;    // T (chains: only the idle lanes' words)
-  static constexpr int LDSW = KPW + NX * NX + ABW + NV * NV + NV + TW + NX + NX + NW + C::RS;   // doubles per instance
+  // The arms without slack, 9 .. 15 states (n = 5, 6, 7): the Schur-complement path of riccati_recursion (ARMB) with
+  // a work area of its own -- image staging | P / Qxx (NX rows of APS doubles: 8-lane groups of a half wavefront on
+  // distinct banks) | [Qux | qu] (NW rows of 16) | Quu (NW rows of 8) | Y operands (8 x 16) | p (16) | dx (2 x 16) |
+  // a word per idle lane (64).  The stage records do not pass through LDS there.
+  static constexpr bool ARMB = LIMG && C::NS == 0 && NX < 16;
+  static constexpr int APS = 24;
+  static constexpr int LDSW_ARM = KPW + APS * NX + 16 * NW + 8 * NW + 128 + 16 + 32 + 64;
+  static constexpr int LDSW = ARMB ? LDSW_ARM
+                                   : KPW + NX * NX + ABW + NV * NV + NV + TW + NX + NX + NW + C::RS;   // doubles per instance
   static constexpr int IMG_SLOTS = LIMG ? (40960 / 8 - LDSW) / KPW : 0;
 };
+
+// v moved between lanes by a DPP control word (quad permutations, row mirrors): full-rate vector moves, no LDS
+// crossbar round trip.  All lanes of the wavefront must be active.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(const double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 8 aligned consecutive lanes a lane belongs to; every lane of the group ends with the total
+__device__ __forceinline__ double dpp_sum8(double v) {
+  v += dpp_move<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_move<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += dpp_move<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of its 8
+  return v;
+}
 
 // Block-tridiagonal Riccati recursion of one instance, LPI lanes.  img: the instance's LDS row (RicLds::LDSW
 // doubles); rb: its stage records (stage 0, stride C::RS; global memory or LDS); kpb: its gain records (stride
@@ -2107,6 +2131,258 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
         *srcdst = k > 0 ? rcn : rcc;
       }
     }
+  }
+  // ---- the arms (pass kernels, one wavefront per instance, n = 5 .. 7 without slack): Schur-complement form ---------
+  // Round 4.  Stamps of the generic path on 1024 arms: stage Hessian 1.46 k, Cholesky + gains 1.44 k, cost-to-go 1.74 k
+  // cycles per backward stage, rollout 2.4 k per forward stage -- 134 LDS reads per lane and stage, five ordering
+  // points.  This path:
+  //   A  lane (i, j) of an n x n grid (8-lane groups) reads the four blocks S, T, T', V of the cost-to-go at (i, j) ONCE
+  //      and forms the seven block entries of [A|B]^T P [A|B] that are needed -- qq, qv, vq, vv in place over P, uq, uv,
+  //      uu for the control block -- instead of every dense entry fetching its four; its record entries come straight
+  //      from the stage record in global memory, requested one stage ahead (the record never passes through LDS);
+  //      g = P rc + p is summed over the 8 lanes of a group by DPP moves, and lanes j = 0, 1, 2 of group i finish
+  //      the gradient entries q_i, v_i, u_i: no separate gradient phase;
+  //   B  Cholesky of Quu in every lane (as before), then only the FORWARD substitution Y = L^-1 [Qux | qu] is on the
+  //      way to the next stage; the backward substitution that yields the gains K | kff goes to the image behind it;
+  //   C  P = Qxx - Y^T Y, p = qx - Y^T y on the matrix cores: two v_mfma_f64_16x16x4_f64 with the SAME register as
+  //      both operands (A = -Y^T, B = Y), accumulated onto [Qxx | qx]; the products of (i, j) and (j, i) are the same
+  //      numbers in the same order, and Qxx is formed symmetrically: the result is symmetric without the 0.5 (a + a^T).
+  // Three ordering points per backward stage, ~55 LDS reads per lane; the image of a stage is written where the
+  // rollout reads it.  The rollout forms dw, nu+ and dx+ from dx alone (one ordering point per stage: the lane of an
+  // entry of dx+ computes the entry of dw it needs itself), as the fused chain path does.
+  if constexpr (RicLds<C, LPI>::ARMB && !SLOTS) {
+    constexpr int n = NQ, PS = RicLds<C, LPI>::APS, QS = 16;
+    constexpr int OFF_KFF = NW * NX, OFF_PT = OFF_KFF + NW, OFF_P = OFF_PT + NP2, OFF_RC = OFF_P + NX;
+    static_assert(NW == n && NX == 2 * n && NX + 1 <= 16 && PS >= 16, "arm path: holonomic chain without slack, one MFMA tile");
+    ldouble *const aP = img + KPW, *const aQux = aP + PS * NX, *const aQuu = aQux + QS * NW, *const aY = aQuu + 8 * NW,
+                 *const ap = aY + 128, *const adx = ap + 16, *const adum = adx + 32;
+    ldouble *const dummy = adum + lane;
+    for (int e = lane; e < PS * NX; e += LPI) aP[e] = 0.0;   // P = 0 behind the last stage (columns NX, NX + 1: gradient / unused)
+    aY[lane] = 0.0; aY[64 + lane] = 0.0;                     // (row 7 and column 15 of the operand tile stay zero)
+    if (lane < 16) ap[lane] = 0.0;
+    // -- lane (gi, gj): block position (ii, jj) ----------------------------------------------------------------
+    const int gi = lane >> 3, gj = lane & 7;
+    const bool gval = gi < n, gon = gval && gj < n;
+    const int ii = gval ? gi : 0, jj = gj < n ? gj : 0;
+    const bool gdiag = gon && ii == jj;
+    const int qlo = ii < jj ? ii : jj, qhi = ii < jj ? jj : ii;
+    const int tq = qlo * n - qlo * (qlo - 1) / 2 + (qhi - qlo);
+    const int jme = gj == 0 ? ii : (gj == 1 ? n + ii : (gj == 2 ? 2 * n + ii : 0));   // gradient entry of lanes gj <= 2
+    const double gc1 = gj == 0 ? 1.0 : (gj == 1 ? h : h2), gc2 = gj == 0 ? 0.0 : (gj == 1 ? 1.0 : h);
+    int ro[8];   // record entries of this lane
+    ro[0] = C::R_Q + tq; ro[1] = C::R_C + tq; ro[2] = C::R_DG + ii; ro[3] = C::R_DG + n + ii;
+    ro[4] = C::R_RC + jj; ro[5] = C::R_RC + n + jj; ro[6] = C::R_Q0 + jme; ro[7] = C::R_Q1 + jme;
+    const int oS = ii * PS + jj, oT = oS + n, oU = (n + ii) * PS + jj, oV = oU + n;
+    ldouble *const dS = gon ? aP + oS : dummy, *const dT = gon ? aP + oT : dummy, *const dU = gon ? aP + oU : dummy,
+                 *const dV = gon ? aP + oV : dummy;
+    ldouble *const dUq = gon ? aQux + ii * QS + jj : dummy, *const dUv = gon ? aQux + ii * QS + n + jj : dummy,
+                 *const dUu = gon ? aQuu + ii * 8 + jj : dummy;
+    ldouble *const dq = (gval && gj <= 2) ? (gj == 2 ? aQux + ii * QS + NX : aP + (gj == 1 ? n + ii : ii) * PS + NX) : dummy;
+    const bool rcw = lane < n;   // lanes (0, jj) put the defect of the stage into the image
+    // -- phase B: gain column of this lane (NX: the gradient column) -------------------------------------------
+    const int bc = lane <= NX ? lane : 0;
+    const bool bon = lane <= NX;
+    ldouble *const dY = bon ? aY + bc : dummy;
+    const int ystr = bon ? 16 : 0;
+    const int koff = lane < NX ? lane : (lane == NX ? OFF_KFF : -1), kstr = lane < NX ? NX : (lane == NX ? 1 : 0);
+    // -- phase C: tile position of this lane -------------------------------------------------------------------
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int c16 = lane & 15, kq = lane >> 4;
+    int co[4], po2[4];
+    bool cin[4];
+    ldouble *cd1[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = kq + 4 * r;
+      const bool rin = row < NX;
+      cin[r] = rin;
+      co[r] = (rin ? row : 0) * PS + c16;
+      cd1[r] = !rin ? dummy : (c16 < NX ? aP + row * PS + c16 : (c16 == NX ? ap + row : dummy));
+      po2[r] = !rin ? -1 : (c16 < NX ? (row <= c16 ? OFF_PT + tri(row, c16) : -1) : (c16 == NX ? OFF_P + row : -1));
+    }
+    // record entries of the stage about to be processed, requested one stage ahead
+    double rn[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) rn[u] = rb[(size_t)(N - 1) * sstr + ro[u]];
+    RST_DECL();
+    for (int k = N - 1; k >= 0; k--) {
+      // image of this stage: stages 1 .. LCAP where the rollout reads them, the others in the staging area (stage 0
+      // stays there; later ones leave for the gain record at the top of the next stage)
+      ldouble *const imk = (k >= 1 && k <= LCAP) ? limg + (size_t)(k - 1) * KPW : img;
+      if (k + 1 < N && k + 1 > LCAP) {   // (uniform) the image of stage k + 1 is complete in the staging area
+        gdouble *const kp1 = kpb + (size_t)(k + 1) * kps;
+#pragma unroll
+        for (int u = 0; u < KPL; u++) {
+          const int e = lane + LPI * u;
+          kp1[e < KPW ? e : KPW] = img[e < KPW ? e : 0];   // (KPW: the record's spare word)
+        }
+      }
+      double rc_[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) rc_[u] = rn[u];
+      {
+        const int kn = k > 0 ? k - 1 : 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) rn[u] = rb[(size_t)kn * sstr + ro[u]];   // travels while this stage is computed
+      }
+      RST(0);
+      // ---- phase A -------------------------------------------------------------------------------------------
+      {
+        const double S = aP[oS], T = aP[oT], U = aP[oU], V = aP[oV], p1 = ap[ii], p2 = ap[n + ii];
+        __builtin_amdgcn_sched_barrier(0);
+        const double rcj = gj < n ? rc_[4] : 0.0, rcnj = gj < n ? rc_[5] : 0.0;
+        const double tv = h * S + T, tu = h2 * S + h * T, bv = h * U + V, bu = h2 * U + h * V;
+        const double qq = S + (rc_[0] - cwt * rc_[1]);
+        const double vq = h * S + U;
+        const double vv = (h * (h * S + (T + U)) + V) + (gdiag ? rc_[2] : 0.0);
+        const double uq = h2 * S + h * U, uv = h2 * tv + h * bv;
+        const double uu = (h2 * tu + h * bu) + (gdiag ? rc_[3] : 0.0);
+        *dS = qq; *dT = tv; *dU = vq; *dV = vv;
+        *dUq = uq; *dUv = uv; *dUu = uu;
+        // g = P rc + p: the group's partial products, summed over its 8 lanes
+        const double g1 = p1 + dpp_sum8(S * rcj + T * rcnj), g2 = p2 + dpp_sum8(U * rcj + V * rcnj);
+        *dq = (rc_[6] - mu * rc_[7]) + (gc1 * g1 + gc2 * g2);
+        *(rcw ? imk + OFF_RC + lane : dummy) = rc_[4];
+        *(rcw ? imk + OFF_RC + n + lane : dummy) = rc_[5];
+      }
+      WSYNC();
+      RST(1);
+      // ---- phase B: Cholesky of Quu (every lane), Y = L^-1 [Qux | qu] (one column per lane), gains -------------
+      v4d acc;
+      {
+        double qw[NW][NW], colv[NW], ac[4];
+#pragma unroll
+        for (int j = 0; j < NW; j++)
+#pragma unroll
+          for (int i = j; i < NW; i++) qw[i][j] = aQuu[i * 8 + j];
+#pragma unroll
+        for (int i = 0; i < NW; i++) colv[i] = aQux[i * QS + bc];
+#pragma unroll
+        for (int r = 0; r < 4; r++) ac[r] = aP[co[r]];   // (accumulator of phase C: arrives during the factorisation)
+        __builtin_amdgcn_sched_barrier(0);
+        double L[NW][NW], invd[NW];
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+          double dg = qw[j][j];
+#pragma unroll
+          for (int l = 0; l < j; l++) dg -= L[j][l] * L[j][l];
+          if (!(dg > 0.0)) chol_ok = false;
+          // 1/sqrt(dg): hardware estimate + two Newton steps (full double precision), then sqrt = dg * rsqrt
+          double inv = __builtin_amdgcn_rsq(dg);
+          inv = inv * (1.5 - 0.5 * dg * inv * inv);
+          inv = inv * (1.5 - 0.5 * dg * inv * inv);
+          L[j][j] = dg * inv;
+          invd[j] = inv;
+#pragma unroll
+          for (int i = j + 1; i < NW; i++) {
+            double s = qw[i][j];
+#pragma unroll
+            for (int l = 0; l < j; l++) s -= L[i][l] * L[j][l];
+            L[i][j] = s * inv;
+          }
+        }
+        double y[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+          double s = colv[i];
+#pragma unroll
+          for (int l = 0; l < i; l++) s -= L[i][l] * y[l];
+          y[i] = s * invd[i];
+          dY[i * ystr] = y[i];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = cin[r] ? ac[r] : 0.0;
+        WSYNC();
+        RST(3);
+        // ---- phase C: [P | p] = [Qxx | qx] - Y^T [Y | y] --------------------------------------------------------
+        const double ya = aY[kq * 16 + c16], yb = aY[(4 + kq) * 16 + c16];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-ya, ya, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-yb, yb, acc, 0, 0, 0);
+        // (behind the matrix instructions: the gains K = -L^-T Y of this lane's column, for the rollout only)
+        double x[NW];
+#pragma unroll
+        for (int i = NW - 1; i >= 0; i--) {
+          double s = y[i];
+#pragma unroll
+          for (int l = i + 1; l < NW; l++) s -= L[l][i] * x[l];
+          x[i] = s * invd[i];
+        }
+        ldouble *const kd = koff >= 0 ? imk + koff : dummy;
+#pragma unroll
+        for (int i = 0; i < NW; i++) kd[i * kstr] = -x[i];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          *cd1[r] = acc[r];
+          *(po2[r] >= 0 ? imk + po2[r] : dummy) = acc[r];
+        }
+      }
+      WSYNC();   // (P, p of this stage are read by the next stage's phase A)
+      RST(4);
+    }
+    if (!chol_ok) return false;
+    // ---- rollout: dw = kff + K dx, nu+ = p + P dx, dx+ = rc + [A|B][dx; dw], one ordering point per stage --------
+    const bool fA = lane < NW, fB = lane >= NW && lane < NW + NX, fC = lane >= NW + NX && lane < NW + 2 * NX;
+    const int fi = fA ? lane : (fB ? lane - NW : (fC ? lane - NW - NX : 0));   // entry of dw / nu+ / dx+
+    const int fw = fC ? (fi < n ? fi : fi - n) : fi;                             // the entry of dw a dx+ lane needs
+    const int foff = fB ? OFF_P + fi : OFF_KFF + fw;
+    int frow[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) frow[j] = fB ? OFF_PT + tri(fi, j) : fw * NX + j;
+    const int fx1 = fi < n ? n + fi : fi;
+    const double fca = fi < n ? h : 0.0, fcb = fi < n ? h2 : h;
+    const size_t dzslot = fA ? (size_t)(NX + lane) : (size_t)fi;
+    if (lane < 32) adx[lane] = 0.0;
+    constexpr int FD = 4;
+    double fvq[FD][KPL];
+    auto fetch_fwd = [&](int k, double (&fv)[KPL]) __attribute__((always_inline)) {
+      const int kk = k < N ? k : N - 1;
+#pragma unroll
+      for (int u = 0; u < KPL; u++) {
+        const int e = lane + LPI * u;
+        fv[u] = kpb[(size_t)kk * kps + (e < KPW ? e : 0)];
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < FD; d++) fetch_fwd(LCAP + 1 + d, fvq[d]);
+    auto fwd_stage = [&](const int k, double (&fv)[KPL], const bool from_mem) __attribute__((always_inline)) {
+      const ldouble *const im = (!from_mem && k > 0) ? limg + (size_t)(k - 1) * KPW : img;
+      if (from_mem) {
+#pragma unroll
+        for (int u = 0; u < KPL; u++) *(lane + LPI * u < KPW ? img + lane + LPI * u : dummy) = fv[u];
+        fetch_fwd(k + FD, fv);
+      }
+      const ldouble *const dxc = adx + 16 * (k & 1);
+      ldouble *const dxn = adx + 16 * ((k & 1) ^ 1);
+      WSYNC();
+      RST(5);
+      double dxv[NX], rowv[NX];
+#pragma unroll
+      for (int j = 0; j < NX; j++) { dxv[j] = dxc[j]; rowv[j] = im[frow[j]]; }
+      double sacc = im[foff];
+      const double rcv = im[OFF_RC + fi], d0 = dxc[fi], d1 = dxc[fx1];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NX; j++) sacc += rowv[j] * dxv[j];
+      // (unconditional stores, idle lanes to the spare word of the stage's gain record)
+      RP *const sink = (RP *)(kpb + (size_t)k * kps + KPW);
+      *((fA || fC) ? so.dz + dzslot * so.SS + (size_t)k * so.KS : sink) = fA ? sacc : d0;
+      *((fB && k >= 1) ? so.nunew + (size_t)fi * so.SS + (size_t)k * so.KS : sink) = sacc;
+      double sx = rcv;
+      sx += d0;
+      sx += fca * d1;
+      sx += fcb * sacc;
+      *((fC && k < N - 1) ? dxn + fi : dummy) = sx;
+      RST(6);
+    };
+    for (int k = 0; k < N && k <= LCAP; k++) fwd_stage(k, fvq[0], false);
+    for (int k0 = LCAP + 1; k0 < N; k0 += FD) {
+#pragma unroll
+      for (int d = 0; d < FD; d++) {
+        if (k0 + d < N) fwd_stage(k0 + d, fvq[d], true);   // (uniform branch)
+      }
+    }
+    RST_FLUSH();
+    return true;
   }
   // ---- generic path (pass kernels; fused kernel of models without a path of their own): per-lane constants ----------
   // idle lanes store to a word of the unused T area (several lanes may share one: the value is never read)
