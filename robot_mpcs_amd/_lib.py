@@ -83,7 +83,8 @@ def _source_hash():
     import hashlib
     root = os.path.dirname(_HERE)
     paths = [os.path.join(_HERE, "csrc", "rmpc_kernels.hip"), os.path.join(_HERE, "csrc", "rmpc_model.hpp"),
-             os.path.join(_HERE, "csrc", "rmpc_spec_gen.hpp"), os.path.join(root, "include", "rmpc.h")]
+             os.path.join(_HERE, "csrc", "rmpc_spec_gen.hpp"), os.path.join(_HERE, "csrc", "rmpc_arm_fused.hpp"),
+             os.path.join(root, "include", "rmpc.h")]
     if not all(os.path.exists(p) for p in paths):
         return None
     h = hashlib.sha256()

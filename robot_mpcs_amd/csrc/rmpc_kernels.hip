@@ -456,11 +456,11 @@ __device__ __forceinline__ void for_range(F &&fn) {
 // array is ptr[slot * SS + loff]: the batch-minor SoA of the pass kernels (SS = N * Bp, loff = k * Bp + b,
 // next stage kstride = Bp) and the per-instance layout of the fused kernel ([instance][slot][32 stages]:
 // SS = 32, loff = k, kstride = 1, pointers advanced to the instance) run the same code.
-template <class RP = gdouble>   // RP: where the stage record and the step live (gdouble, or ldouble in the fused kernel)
+template <class RP = gdouble, class SP = RP>   // RP / SP: where the stage record / the step live (gdouble, or ldouble in the fused kernels)
 struct SweepIO {
   const gdouble *zc, *tc, *lc, *nc, *pp, *gro, *jqo;   // iterate (current buffer), parameters
   gdouble *zn, *tn, *ln, *nn, *grn, *jqn, *gfa;        // trial point (other buffer), cost gradient
-  const RP *dzp, *nup;                                 // step
+  const SP *dzp, *nup;                                 // step
   RP *rec;                                             // this lane's stage record
   size_t SS;
   unsigned loff, kstride;
@@ -1632,11 +1632,13 @@ struct FusedSlots {
   static constexpr int GS = (NEED + 7) / 8 * 8 + 2;
 };
 
-template <class C, int LPI, bool SLOTS = false, class RP = gdouble, bool OWNER = false>
+template <class C, int LPI, bool SLOTS = false, class RP = gdouble, bool OWNER = false, class SP = RP>
 __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, const double mu, const bool usec, const int lane,
                                                   ldouble *const img, const RP *const rb, gdouble *const kpb,
-                                                  const int kps, const StepOut<RP> so, ldouble *const slots = nullptr,
-                                                  ldouble *const limg = nullptr) {
+                                                  const int kps, const StepOut<SP> so, ldouble *const slots = nullptr,
+                                                  ldouble *const limg = nullptr, const int lcap_rt = -1) {
+  // SP: where the step goes (the fused arm kernel keeps it in LDS while its records are in global memory);
+  // lcap_rt >= 0: number of gain-image slots behind limg (the arm path; otherwise RicLds::IMG_SLOTS)
   // SLOTS: rb == slots (records), gains go to the slots as well (kpb unused)
   // limg (RicLds::LIMG): RicLds::IMG_SLOTS gain images of KPW doubles in LDS, stages 1 .. IMG_SLOTS
   constexpr int GS = FusedSlots<C>::GS;
@@ -2206,6 +2208,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     ldouble *const aP = img + KPW, *const aQux = aP + PS * NX, *const aQuu = aQux + QS * NW, *const aY = aQuu + 8 * NW,
                  *const ap = aY + 128, *const adx = ap + 16, *const adum = adx + 32;
     ldouble *const dummy = adum + lane;
+    const int LCAPr = lcap_rt >= 0 ? lcap_rt : LCAP;   // stages 1 .. LCAPr keep their image in LDS
     for (int e = lane; e < PS * NX; e += LPI) aP[e] = 0.0;   // P = 0 behind the last stage (columns NX, NX + 1: gradient / unused)
     aY[lane] = 0.0; aY[64 + lane] = 0.0;                     // (row 7 and column 15 of the operand tile stay zero)
     if (lane < 16) ap[lane] = 0.0;
@@ -2257,8 +2260,8 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     for (int k = N - 1; k >= 0; k--) {
       // image of this stage: stages 1 .. LCAP where the rollout reads them, the others in the staging area (stage 0
       // stays there; later ones leave for the gain record at the top of the next stage)
-      ldouble *const imk = (k >= 1 && k <= LCAP) ? limg + (size_t)(k - 1) * KPW : img;
-      if (k + 1 < N && k + 1 > LCAP) {   // (uniform) the image of stage k + 1 is complete in the staging area
+      ldouble *const imk = (k >= 1 && k <= LCAPr) ? limg + (size_t)(k - 1) * KPW : img;
+      if (k + 1 < N && k + 1 > LCAPr) {   // (uniform) the image of stage k + 1 is complete in the staging area
         gdouble *const kp1 = kpb + (size_t)(k + 1) * kps;
 #pragma unroll
         for (int u = 0; u < KPL; u++) {
@@ -2392,7 +2395,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       }
     };
 #pragma unroll
-    for (int d = 0; d < FD; d++) fetch_fwd(LCAP + 1 + d, fvq[d]);
+    for (int d = 0; d < FD; d++) fetch_fwd(LCAPr + 1 + d, fvq[d]);
     auto fwd_stage = [&](const int k, double (&fv)[KPL], const bool from_mem) __attribute__((always_inline)) {
       const ldouble *const im = (!from_mem && k > 0) ? limg + (size_t)(k - 1) * KPW : img;
       if (from_mem) {
@@ -2413,7 +2416,9 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
 #pragma unroll
       for (int j = 0; j < NX; j++) sacc += rowv[j] * dxv[j];
       // (unconditional stores, idle lanes to the spare word of the stage's gain record)
-      RP *const sink = (RP *)(kpb + (size_t)k * kps + KPW);
+      SP *sink;
+      if constexpr (std::is_same<SP, ldouble>::value) sink = dummy;
+      else sink = (SP *)(kpb + (size_t)k * kps + KPW);
       *((fA || fC) ? so.dz + dzslot * so.SS + (size_t)k * so.KS : sink) = fA ? sacc : d0;
       *((fB && k >= 1) ? so.nunew + (size_t)fi * so.SS + (size_t)k * so.KS : sink) = sacc;
       double sx = rcv;
@@ -2423,8 +2428,8 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       *((fC && k < N - 1) ? dxn + fi : dummy) = sx;
       RST(6);
     };
-    for (int k = 0; k < N && k <= LCAP; k++) fwd_stage(k, fvq[0], false);
-    for (int k0 = LCAP + 1; k0 < N; k0 += FD) {
+    for (int k = 0; k < N && k <= LCAPr; k++) fwd_stage(k, fvq[0], false);
+    for (int k0 = LCAPr + 1; k0 < N; k0 += FD) {
 #pragma unroll
       for (int d = 0; d < FD; d++) {
         if (k0 + d < N) fwd_stage(k0 + d, fvq[d], true);   // (uniform branch)
@@ -2964,7 +2969,9 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       // (unconditional stores, idle lanes to the spare word of the stage's gain record: behind a predicated store the
       //  compiler no longer knows how many requests are in flight and waits for ALL of them -- the images of the next
       //  stages included -- before it touches the oldest)
-      RP *const sink = (RP *)(kpb + (size_t)k * kps + KPW);
+      SP *sink;
+      if constexpr (std::is_same<SP, ldouble>::value) sink = gdummy;
+      else sink = (SP *)(kpb + (size_t)k * kps + KPW);
       *((fact && !fisw && k >= 1) ? so.nunew + (size_t)fi * so.SS + (size_t)k * so.KS : sink) = sacc;
       *(fact ? so.dz + (size_t)(fisw ? NX + lane : lane - NW) * so.SS + (size_t)k * so.KS : sink) = dzv;
     }
@@ -3349,7 +3356,7 @@ __global__ __launch_bounds__(64) void k_riccati_lane(const DevModel M, const Ws 
 // k_step: slack / multiplier steps and step-length partials, stage parallel
 // ===========================================================================
 // What one lane of the step kernel addresses (same convention as SweepIO).
-template <class RP = gdouble>
+template <class RP = gdouble>   // RP: where the step lives
 struct StepIO {
   const gdouble *zc, *tc, *lc, *grow, *Jq, *gfa;
   const RP *dz;
@@ -4128,6 +4135,8 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1), di
 #endif
 }
 
+#include "rmpc_arm_fused.hpp"   // the arms in one launch (k_fused_arm: a wavefront per instance, a stage per P lanes)
+
 // Launch order of a fused launch: the instances sorted by a key (the passes of their previous solve for a warm start,
 // k_difficulty's estimate for a cold one), largest first (counting sort, one block; the order inside a bucket is
 // whatever the atomics give -- it changes which instances share a wavefront, never what an instance computes).
@@ -4626,6 +4635,27 @@ int launch_fused_t(rmpc_handle *h, int B, const double *d_xinit, const double *d
   return 0;
 }
 template <class C>
+int launch_fused_arm_t(rmpc_handle *h, int B, const double *d_xinit, const double *d_x0, const double *d_params,
+                       double *d_zout, int *d_exit, int *d_iters, double *d_kkt, double *d_obj, hipStream_t st, int cap) {
+  if constexpr (C::ARM_FUSED) {
+    const int warm = (h->warm_mode && h->have_duals) ? 1 : 0;
+    if (h->F.rs != C::RS) return fail("stage-record layout mismatch between the workspace and the kernel variant");
+    const int use_order = (warm && !h->env_no_order) ? 1 : 0;
+    // the grid is the chip (one wavefront per SIMD), the batch a queue its wavefronts drain
+    const int grid = B < h->fused_grid ? B : h->fused_grid;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void *)k_fused_arm<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ArmLds<C>::TOTAL * 8);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((k_fused_arm<C, 2>), dim3(grid), dim3(64), ArmLds<C>::TOTAL * 8, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
+                       d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm, use_order);
+    return 0;
+  } else {
+    return fail("no fused arm kernel for this model");
+  }
+}
+template <class C>
 int launch_advance(rmpc_handle *h, int B, const double *d_z_prev, const int *ef, double *d_xinit, double *d_x0, int previous_plan,
                    hipStream_t st) {
   hipLaunchKernelGGL((k_advance<C>), dim3((B + kAdvanceIB - 1) / kAdvanceIB), dim3(256), 0, st, h->M, d_z_prev, d_xinit, d_x0, B,
@@ -4654,6 +4684,7 @@ int launch_retarget(rmpc_handle *h, int B, double *d_xinit, double *d_x0, const 
   KW int launch_advance<Cfg<R, NQ, NS>> RMPC_SIG_ADV;                 \
   KW int launch_retarget<Cfg<R, NQ, NS>> RMPC_SIG_RET;
 #define RMPC_INST_F(KW, R, NQ, NS) KW int launch_fused_t<Cfg<R, NQ, NS>, RtView> RMPC_SIG_FUSED;
+#define RMPC_INST_FA(KW, R, NQ, NS) KW int launch_fused_arm_t<Cfg<R, NQ, NS>> RMPC_SIG_FUSED;
 static_assert(variant_id(RMPC_ROBOT_CHAIN, 3, 0) == 0, "instantiation list out of step with RMPC_VARIANTS");
 #if (RMPC_DEV_VARIANTS >> 0) & 1
 RMPC_INST(template, RMPC_ROBOT_CHAIN, 3, 0) RMPC_INST_F(template, RMPC_ROBOT_CHAIN, 3, 0)
@@ -4668,9 +4699,9 @@ RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 3, 1) RMPC_INST_F(extern template, 
 #endif
 static_assert(variant_id(RMPC_ROBOT_CHAIN, 7, 0) == 2, "instantiation list out of step with RMPC_VARIANTS");
 #if (RMPC_DEV_VARIANTS >> 2) & 1
-RMPC_INST(template, RMPC_ROBOT_CHAIN, 7, 0)
+RMPC_INST(template, RMPC_ROBOT_CHAIN, 7, 0) RMPC_INST_FA(template, RMPC_ROBOT_CHAIN, 7, 0)
 #elif (RMPC_ALL_VARIANTS >> 2) & 1
-RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 7, 0)
+RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 7, 0) RMPC_INST_FA(extern template, RMPC_ROBOT_CHAIN, 7, 0)
 #endif
 static_assert(variant_id(RMPC_ROBOT_CHAIN, 7, 1) == 3, "instantiation list out of step with RMPC_VARIANTS");
 #if (RMPC_DEV_VARIANTS >> 3) & 1
@@ -4704,15 +4735,15 @@ RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 4, 0)
 #endif
 static_assert(variant_id(RMPC_ROBOT_CHAIN, 5, 0) == 8, "instantiation list out of step with RMPC_VARIANTS");
 #if (RMPC_DEV_VARIANTS >> 8) & 1
-RMPC_INST(template, RMPC_ROBOT_CHAIN, 5, 0)
+RMPC_INST(template, RMPC_ROBOT_CHAIN, 5, 0) RMPC_INST_FA(template, RMPC_ROBOT_CHAIN, 5, 0)
 #elif (RMPC_ALL_VARIANTS >> 8) & 1
-RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 5, 0)
+RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 5, 0) RMPC_INST_FA(extern template, RMPC_ROBOT_CHAIN, 5, 0)
 #endif
 static_assert(variant_id(RMPC_ROBOT_CHAIN, 6, 0) == 9, "instantiation list out of step with RMPC_VARIANTS");
 #if (RMPC_DEV_VARIANTS >> 9) & 1
-RMPC_INST(template, RMPC_ROBOT_CHAIN, 6, 0)
+RMPC_INST(template, RMPC_ROBOT_CHAIN, 6, 0) RMPC_INST_FA(template, RMPC_ROBOT_CHAIN, 6, 0)
 #elif (RMPC_ALL_VARIANTS >> 9) & 1
-RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 6, 0)
+RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 6, 0) RMPC_INST_FA(extern template, RMPC_ROBOT_CHAIN, 6, 0)
 #endif
 static_assert(variant_id(RMPC_ROBOT_CHAIN, 8, 0) == 10, "instantiation list out of step with RMPC_VARIANTS");
 #if (RMPC_DEV_VARIANTS >> 10) & 1
@@ -4722,6 +4753,7 @@ RMPC_INST(extern template, RMPC_ROBOT_CHAIN, 8, 0)
 #endif
 #undef RMPC_INST
 #undef RMPC_INST_F
+#undef RMPC_INST_FA
 
 #if RMPC_TU_MAIN
 
@@ -4783,6 +4815,23 @@ static int build_tables(const rmpc_desc &d, const DevModel &M, DevTables &T, std
   for (int q = 0; q < M.nlb && ok; q++, i++) ok = add_var_row(M.lb_var[q], i, +1, -1, M.lb_val[q], 0, -1, 0);
   for (int q = 0; q < M.nub && ok; q++, i++) ok = add_var_row(M.ub_var[q], i, -1, -1, M.ub_val[q], 0, -1, 0);
   if (!ok) { err = "more than 4 limit / bound rows on one variable"; return -1; }
+  // packed copies (fused arm kernel)
+  for (int j = 0; j < RMPC_NV_MAX; j++)
+    for (int u = 0; u < kVarRows; u++) {
+      int w = 0;
+      if (T.v_row[j][u] >= 0 && T.v_row[j][u] < 256 && T.v_poff[j][u] < 65536) {
+        w = T.v_row[j][u] | (1 << 8) | ((T.v_sgn[j][u] < 0 ? 1 : 0) << 9) | ((T.v_first[j][u] ? 1 : 0) << 10) |
+            ((T.v_poff[j][u] >= 0 ? 1 : 0) << 11) | ((T.v_mod[j][u] >= 0 ? T.v_mod[j][u] & 7 : 0) << 12) |
+            ((T.v_poff[j][u] >= 0 ? T.v_poff[j][u] : 0) << 16);
+      }
+      T.v_desc[j][u] = w;
+    }
+  for (int q = 0; q < T.nfkrows; q++)
+    T.fk_desc[q] = (T.fk_row[q] & 255) | ((T.fk_kind[q] & 3) << 8) | ((T.fk_obst[q] & 63) << 10) | ((T.fk_mod[q] & 7) << 16) |
+                   ((T.fk_first[q] ? 1 : 0) << 19) | ((T.fk_idx[q] & 63) << 20);
+  T.slot_rows_max = 0;
+  for (int s = 0; s < kMaxSlots; s++)
+    if (T.slot_row_begin[s + 1] - T.slot_row_begin[s] > T.slot_rows_max) T.slot_rows_max = T.slot_row_begin[s + 1] - T.slot_row_begin[s];
   return 0;
 }
 
@@ -5213,16 +5262,23 @@ static void prof_collect(rmpc_handle *h) {
 
 // ---- fused path ------------------------------------------------------------------------------------------
 static int fused_columns(int max_batch) { return (max_batch + 1) / 2 * 2; }
+static bool arm_fused_model(const DevModel &M) {   // = Cfg::ARM_FUSED of the model's variant
+  return M.robot == RMPC_ROBOT_CHAIN && M.ns == 0 && M.nx > 8 && M.nx < 16;
+}
 static size_t carve_fused(const DevModel &M, int Bcap, void *base, FusedWs &F) {
   Carver c(base);
   const size_t S = (size_t)Bcap * kFusedStages;
+  const bool arm = arm_fused_model(M);
   F.nv = M.nv; F.m = M.m; F.nx = M.nx; F.npar = M.npar;
-  F.nhs = M.nh > 0 ? M.nh : 1; F.njqs = M.nfk > 0 ? M.nfk * M.n : 1;
+  // (the arms: one spare row behind the general rows' values, where the rows that keep no value are stored)
+  F.nhs = arm ? M.nh + 1 : (M.nh > 0 ? M.nh : 1); F.njqs = M.nfk > 0 ? M.nfk * M.n : 1;
   F.p = c.take<double>(S * M.npar);
+  // (the arms: F.m counts the spare row behind the slacks / multipliers, where the rows a joint does not have are evaluated)
+  if (arm) F.m = M.m + 1;
   for (int i = 0; i < 2; i++) {
     F.z[i] = c.take<double>(S * M.nv);
-    F.t[i] = c.take<double>(S * M.m);
-    F.lam[i] = c.take<double>(S * M.m);
+    F.t[i] = c.take<double>(S * F.m);
+    F.lam[i] = c.take<double>(S * F.m);
     F.nu[i] = c.take<double>(S * M.nx);
     F.grow[i] = c.take<double>(S * F.nhs);
     F.Jq[i] = c.take<double>(S * F.njqs);
@@ -5230,11 +5286,12 @@ static size_t carve_fused(const DevModel &M, int Bcap, void *base, FusedWs &F) {
   F.dz = c.take<double>(S * M.nv);
   F.nunew = c.take<double>(S * M.nx);
   F.gfa = c.take<double>(S * M.nv);
-  F.wlam = c.take<double>(S * M.m);
+  F.wlam = c.take<double>(S * F.m);
   F.wnu = c.take<double>(S * M.nx);
   F.wmu = c.take<double>(Bcap);
   F.rs = rec_layout(M).rs;
-  F.R = c.take<double>((size_t)Bcap * M.N * F.rs);
+  // (the arms: a record slot for every one of the 32 stage columns -- lanes without a stage work on the padding columns)
+  F.R = c.take<double>((size_t)Bcap * (arm ? kFusedStages : M.N) * F.rs);
   F.kps = (M.nw * M.nx + M.nw + M.nx * (M.nx + 1) / 2 + M.nx + M.nx + 8) / 8 * 8;
   F.KP = c.take<double>((size_t)Bcap * M.N * F.kps);
   F.passes = c.take<int>(64);
@@ -5244,7 +5301,19 @@ static size_t carve_fused(const DevModel &M, int Bcap, void *base, FusedWs &F) {
   F.stamps = c.take<long long>((size_t)Bcap * 8);
   return (c.off + 255) & ~(size_t)255;
 }
-static bool fused_supported(int variant, const DevModel &M) {
+// k_fused_arm reads the row STRUCTURE of a joint's variables (which limit / bound rows q_a, v_a, u_a have, whether a
+// row's limit is a parameter, its sign) from joint 0 and takes scalar branches on it; only row index, parameter offset
+// and module differ from joint to joint.  True for every module of the reference (they loop over all joints:
+// JointLimitConstraints.py:8-31, InputLimitConstraints.py:7-29, bounds mpcModel.py:91-104); checked here all the same.
+static bool arm_rows_uniform(const DevModel &M, const DevTables &T) {
+  const int keep = (1 << 8) | (1 << 9) | (1 << 11);
+  for (int a = 1; a < M.n; a++)
+    for (int c = 0; c < 3; c++)
+      for (int u = 0; u < kVarRows; u++)
+        if ((T.v_desc[a + c * M.n][u] & keep) != (T.v_desc[c * M.n][u] & keep)) return false;
+  return true;
+}
+static bool fused_supported(int variant, const DevModel &M, const DevTables &T) {
   // chain n = 3 and the diff-drive base, horizons that fit the 32 lanes of an instance.  The arm stays with the pass
   // kernels: in the fused kernel (measured twice in round 2, the second time with the recursion as a real function) a
   // pass takes 670 k cycles -- its recursion on the 32 lanes of an instance alone 347 k, twice the 64-lane pass kernel
@@ -5253,9 +5322,10 @@ static bool fused_supported(int variant, const DevModel &M) {
   // the 7 x 7 factorisation and the cost-to-go update, not by its ordering points.
   bool ok = false;
 #define RMPC_FS(ID, R, NQ, NS) \
-  if (variant == ID) ok = Cfg<R, NQ, NS>::FUSED_OK;
+  if (variant == ID) ok = Cfg<R, NQ, NS>::FUSED_OK || Cfg<R, NQ, NS>::ARM_FUSED;
   RMPC_VARIANTS(RMPC_FS)
 #undef RMPC_FS
+  if (ok && arm_fused_model(M) && !arm_rows_uniform(M, T)) ok = false;
   return ok && M.N <= kFusedStages;
 }
 
@@ -5276,6 +5346,13 @@ static int launch_fused(rmpc_handle *h, int B, const double *d_xinit, const doub
   }
   RMPC_VARIANTS(RMPC_V)
 #undef RMPC_V
+#define RMPC_VA(ID, R, NQ, NS)                                                                                      \
+  if constexpr (Cfg<R, NQ, NS>::ARM_FUSED && variant_available<R, NQ, NS>()) {                                      \
+    if (rc == -2 && h->variant == ID)                                                                               \
+      rc = launch_fused_arm_t<Cfg<R, NQ, NS>>(h, B, d_xinit, d_x0, d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, st, cap); \
+  }
+  RMPC_VARIANTS(RMPC_VA)
+#undef RMPC_VA
   if (rc == 0) {
     // the order of the NEXT warm-started launch, right behind this one (in front of it the little kernel would wait
     // for a free SIMD whenever another handle's fused launch fills the chip: 130 us in the fleet loop)
@@ -5455,7 +5532,7 @@ int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch) {
   const int Bp = (max_batch + 63) / 64 * 64;
   const int Bpc = compact_columns(max_batch);
   FusedWs F;
-  const size_t fused = fused_supported(variant_of(*desc), M) ? carve_fused(M, fused_columns(max_batch), nullptr, F) : 0;
+  const size_t fused = fused_supported(variant_of(*desc), M, T) ? carve_fused(M, fused_columns(max_batch), nullptr, F) : 0;
   return (int64_t)(carve(M, Bp, passes_cap(M), nullptr, W) + (Bpc ? carve(M, Bpc, 0, nullptr, W) : 0) + fused);
 }
 
@@ -5493,7 +5570,7 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   h->Bpc = compact_columns(max_batch);
   const size_t big = carve(h->M, h->Bp, h->max_passes, nullptr, tmp);
   const size_t small = h->Bpc ? carve(h->M, h->Bpc, 0, nullptr, tmp) : 0;
-  h->fused = fused_supported(h->variant, h->M) && !getenv("RMPC_NO_FUSED");   // (debugging switch: pass kernels only)
+  h->fused = fused_supported(h->variant, h->M, h->T) && !getenv("RMPC_NO_FUSED");   // (debugging switch: pass kernels only)
   FusedWs ftmp;
   h->ws_bytes = big + small + (h->fused ? carve_fused(h->M, fused_columns(max_batch), nullptr, ftmp) : 0);
   e = hipMalloc(&h->ws_base, h->ws_bytes);
@@ -5511,9 +5588,12 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   if (h->fused) carve_fused(h->M, fused_columns(max_batch), (char *)h->ws_base + big + small, h->F);
   // (the row tables, and behind them a copy of the fused workspace's pointer block: the phase functions of the
   //  fused kernel take the instance's bases from there instead of receiving two dozen pointers per call)
-  e = hipMalloc((void **)&h->d_T, sizeof(DevTables) + sizeof(FusedWs));
+  // behind the row tables: the fused workspace block and a copy of the model (ArmBlock: the phase functions of the fused
+  // kernels read both through uniform pointers)
+  e = hipMalloc((void **)&h->d_T, sizeof(DevTables) + sizeof(ArmBlock));
   if (e == hipSuccess) e = hipMemcpy(h->d_T, &h->T, sizeof(DevTables), hipMemcpyHostToDevice);
   if (e == hipSuccess && h->fused) e = hipMemcpy((void *)(h->d_T + 1), &h->F, sizeof(FusedWs), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy((char *)(h->d_T + 1) + offsetof(ArmBlock, M), &h->M, sizeof(DevModel), hipMemcpyHostToDevice);
   if (e != hipSuccess) { (void)hipFree(h->ws_base); delete h; return fail(std::string("row tables: ") + hipGetErrorString(e)); }
   e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_active, sizeof(int), hipHostMallocDefault);

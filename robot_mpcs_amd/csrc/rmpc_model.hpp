@@ -82,6 +82,14 @@ struct DevTables {
   int v_mod[RMPC_NV_MAX][kVarRows];                  // owning module, -1 for simple bounds
   int v_first[RMPC_NV_MAX][kVarRows];                // first row of its module (inverse-barrier objective)
   double v_val[RMPC_NV_MAX][kVarRows];               // constant bound value
+  // the same tables packed, one word per row, for lanes that index them with a per-lane variable / row (the (stage,
+  // part) lanes of the fused arm kernel: one vector request instead of six).  v_desc: bits 0-7 storage index, 8 present,
+  // 9 sign negative, 10 first row of its module, 11 general row (limit from the parameters), 12-14 module, 16-31
+  // parameter offset.  fk_desc: bits 0-7 storage index, 8-9 kind, 10-15 obstacle, 16-18 module, 19 first row of its
+  // module, 20-25 index among the FK rows.
+  int v_desc[RMPC_NV_MAX][kVarRows];
+  int fk_desc[kMaxFkRows];
+  int slot_rows_max;                                 // most FK rows of one slot
 };
 
 // ---------------------------------------------------------------------------
@@ -118,6 +126,12 @@ struct RtView {
   __device__ __forceinline__ int v_mod(int j, int u) const { return T.v_mod[j][u]; }
   __device__ __forceinline__ int v_first(int j, int u) const { return T.v_first[j][u]; }
   __device__ __forceinline__ double v_val(int j, int u) const { return T.v_val[j][u]; }
+  __device__ __forceinline__ int v_desc(int j, int u) const { return T.v_desc[j][u]; }
+  __device__ __forceinline__ int fk_desc(int r) const { return T.fk_desc[r]; }
+  __device__ __forceinline__ int slot_rows_max() const { return T.slot_rows_max; }
+  __device__ __forceinline__ int n_rows() const { return M.m; }
+  __device__ __forceinline__ int n_general() const { return M.nh; }
+  __device__ __forceinline__ int n_fk() const { return M.nfk; }
   __device__ __forceinline__ int off_r_body() const { return M.off_r_body; }
   __device__ __forceinline__ int off_obst() const { return M.off_obst; }
   __device__ __forceinline__ int off_lin() const { return M.off_lin; }
@@ -133,6 +147,43 @@ struct RtView {
   __device__ __forceinline__ double joint_rot(int j, int c) const { return M.joint_rot[j][c]; }
   __device__ __forceinline__ double joint_axis(int j, int c) const { return M.joint_axis[j][c]; }
   __device__ __forceinline__ double dd_off(int f, int c) const { return M.dd_off[f][c]; }
+};
+
+// The runtime tables for the phase FUNCTIONS of the fused arm kernel: model and tables are copies in device memory,
+// reached through uniform pointers in the constant address space (a callee gets its arguments in vector registers;
+// through the constant address space the tables still come by scalar loads).  Same accessors as RtView.
+struct GView {
+  static constexpr bool SPEC = false;
+  typedef const __attribute__((address_space(4))) DevModel cModel;
+  typedef const __attribute__((address_space(4))) DevTables cTables;
+  cModel *M;
+  cTables *T;
+  __device__ __forceinline__ GView(cModel *m, cTables *t) : M(m), T(t) {}
+  __device__ __forceinline__ int nslots() const { return T->nslots; }
+  __device__ __forceinline__ int slot_fa(int s) const { return T->slot_fa[s]; }
+  __device__ __forceinline__ int slot_fb(int s) const { return T->slot_fb[s]; }
+  __device__ __forceinline__ int slot_row_begin(int s) const { return T->slot_row_begin[s]; }
+  __device__ __forceinline__ int nfkrows() const { return T->nfkrows; }
+  __device__ __forceinline__ double v_val(int j, int u) const { return T->v_val[j][u]; }
+  __device__ __forceinline__ int v_desc(int j, int u) const { return T->v_desc[j][u]; }
+  __device__ __forceinline__ int fk_desc(int r) const { return T->fk_desc[r]; }
+  __device__ __forceinline__ int slot_rows_max() const { return T->slot_rows_max; }
+  __device__ __forceinline__ int n_rows() const { return M->m; }
+  __device__ __forceinline__ int n_general() const { return M->nh; }
+  __device__ __forceinline__ int n_fk() const { return M->nfk; }
+  __device__ __forceinline__ int off_r_body() const { return M->off_r_body; }
+  __device__ __forceinline__ int off_obst() const { return M->off_obst; }
+  __device__ __forceinline__ int off_lin() const { return M->off_lin; }
+  __device__ __forceinline__ int off_wu() const { return M->off_wu; }
+  __device__ __forceinline__ int off_goal() const { return M->off_goal; }
+  __device__ __forceinline__ int off_wgoal() const { return M->off_wgoal; }
+  __device__ __forceinline__ int off_wconstr() const { return M->off_wconstr; }
+  __device__ __forceinline__ int has_goal() const { return M->has_goal; }
+  __device__ __forceinline__ int has_avoid() const { return M->has_avoid; }
+  __device__ __forceinline__ int joint_type(int j) const { return M->joint_type[j]; }
+  __device__ __forceinline__ double joint_xyz(int j, int c) const { return M->joint_xyz[j][c]; }
+  __device__ __forceinline__ double joint_rot(int j, int c) const { return M->joint_rot[j][c]; }
+  __device__ __forceinline__ double joint_axis(int j, int c) const { return M->joint_axis[j][c]; }
 };
 
 struct Vec3 {
@@ -200,6 +251,9 @@ struct Cfg {
   // leave room for two wavefronts per CU only -- they go through the instance's block of the workspace)
   static constexpr bool FUSED_REC_LDS = (ROBOT_ == RMPC_ROBOT_CHAIN) && (NQ_ <= 3);
   static constexpr bool FUSED_OK = !(ROBOT_ == RMPC_ROBOT_CHAIN && NQ_ > 3);   // models k_fused is built for
+  // the arms k_fused_arm is built for (rmpc_arm_fused.hpp): holonomic chains without slack whose state and gradient
+  // column fit one 16 x 16 tile of the matrix cores (n = 5, 6, 7) -- the models of riccati_recursion's arm path
+  static constexpr bool ARM_FUSED = (ROBOT_ == RMPC_ROBOT_CHAIN) && NS_ == 0 && NX > 8 && NX < 16;
 };
 
 // ---------------------------------------------------------------------------
@@ -311,7 +365,7 @@ struct Kin {
     return P;
   }
 
- private:
+ public:   // (also used by the part-wise sweep of the fused arm kernel)
   __device__ __forceinline__ static void mul33(double (&R)[9], const double *Bm) {
     double r[9];
 #pragma unroll

@@ -68,6 +68,36 @@ def test_solve_matches_oracle(rt, name, B, seed):
     np.testing.assert_allclose(gpu["obj"], cpu["obj"], rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("name,B,seed", [("cfg4", 96, 71), ("wc_panda", 40, 72), ("chain5", 48, 73), ("chain6", 48, 74)])
+def test_arm_pass_kernels_match_oracle(rt, name, B, seed, monkeypatch):
+    """The arms with 5 .. 7 joints run k_fused_arm by default (round 4); their pass kernels -- what horizons beyond 32
+    stages use, with the Schur-complement recursion of round 4 -- are kept under test through RMPC_NO_FUSED=1."""
+    monkeypatch.setenv("RMPC_NO_FUSED", "1")
+    sc = rt["make_scenario"](name, B=B, seed=seed)
+    cpu = rt["Oracle"](sc.desc).solve_batch(sc.xinit, sc.x0, sc.params)
+    s = rt["Solver"](sc.desc, max_batch=B)
+    assert not s.is_fused()
+    gpu = s.solve(sc.xinit, sc.x0, sc.params)
+    s.close()
+    _check_plan(gpu, cpu, sc.desc["nx"] + sc.desc["ns"])
+
+
+@pytest.mark.parametrize("name,B,seed", [("cfg2", 192, 81), ("chain2", 96, 82)])
+def test_lane_per_instance_recursion_matches_oracle(rt, name, B, seed, monkeypatch):
+    """k_riccati_lane (one lane per instance: the default recursion of the pass kernels for lists of at least 16384
+    instances of a small chain) forced for a small batch (RMPC_RIC_LANE=2, RMPC_NO_FUSED=1): flags, iteration counts and
+    plans against the oracle like every other path."""
+    monkeypatch.setenv("RMPC_NO_FUSED", "1")
+    monkeypatch.setenv("RMPC_RIC_LANE", "2")
+    sc = rt["make_scenario"](name, B=B, seed=seed)
+    cpu = rt["Oracle"](sc.desc).solve_batch(sc.xinit, sc.x0, sc.params)
+    s = rt["Solver"](sc.desc, max_batch=B)
+    assert not s.is_fused()
+    gpu = s.solve(sc.xinit, sc.x0, sc.params)
+    s.close()
+    _check_plan(gpu, cpu, sc.desc["nx"] + sc.desc["ns"])
+
+
 @pytest.mark.parametrize("name,B,seed", [("cfg2", 300, 61), ("wc_point", 200, 62), ("chain2", 200, 63), ("cfg3", 200, 64)])
 def test_queue_and_cold_order_on_a_tiny_grid(rt, name, B, seed, monkeypatch):
     """RMPC_FUSED_GRID=4: eight half-wavefronts drain a queue of hundreds of instances, and a cold launch of the
@@ -553,31 +583,35 @@ def test_pass_budget_cuts_only_the_unfinished(rt, name, B, budget):
 
 
 def test_is_fused_tells_which_solves_need_no_host_look(rt, monkeypatch):
-    """rmpc_is_fused: the point robot and the diff-drive base (N <= 32) solve in one launch, the arm and long horizons
-    through the pass kernels; RMPC_NO_FUSED=1 (read at rmpc_create) sends everything through the pass kernels."""
+    """rmpc_is_fused: the point robot, the diff-drive base and (round 4: k_fused_arm) the arms with 5 .. 7 joints solve in
+    one launch when N <= 32; arms with 4 or 8 joints, arms with the slack variable and long horizons go through the pass
+    kernels; RMPC_NO_FUSED=1 (read at rmpc_create) sends everything through the pass kernels."""
     monkeypatch.delenv("RMPC_NO_FUSED", raising=False)
-    want = {"cfg2": True, "cfg3": True, "cfg4": False, "chain2": True, "chain5": False}
+    want = {"cfg2": True, "cfg3": True, "cfg4": True, "chain2": True, "chain5": True, "chain6": True, "chain4": False, "chain8": False}
     for name, fused in want.items():
         sc = rt["make_scenario"](name, B=4, seed=1)
         s = rt["Solver"](sc.desc, max_batch=4)
         assert s.is_fused() == fused, name
         s.close()
-    sc = rt["make_scenario"]("cfg2", B=4, seed=1, time_horizon=40)
-    s = rt["Solver"](sc.desc, max_batch=4)
-    assert not s.is_fused()
-    s.close()
+    for name in ("cfg2", "cfg4"):
+        sc = rt["make_scenario"](name, B=4, seed=1, time_horizon=40)
+        s = rt["Solver"](sc.desc, max_batch=4)
+        assert not s.is_fused(), name
+        s.close()
     monkeypatch.setenv("RMPC_NO_FUSED", "1")
-    sc = rt["make_scenario"]("cfg2", B=4, seed=1)
-    s = rt["Solver"](sc.desc, max_batch=4)
-    assert not s.is_fused()
-    s.close()
+    for name in ("cfg2", "cfg4"):
+        sc = rt["make_scenario"](name, B=4, seed=1)
+        s = rt["Solver"](sc.desc, max_batch=4)
+        assert not s.is_fused(), name
+        s.close()
 
 
-def test_budgeted_pass_kernel_solve_needs_no_host_look(rt):
-    """rmpc_is_async: under a pass budget the arm's solve is enqueued whole (no host look) and returns before the
-    device has finished; its results are those of the host-driven loop under the same budget (bit for bit), the
-    non-empty passes are counted on the device, and the call is ordered with the caller's stream."""
+def test_budgeted_pass_kernel_solve_needs_no_host_look(rt, monkeypatch):
+    """rmpc_is_async: under a pass budget a solve of the pass kernels (the arm with RMPC_NO_FUSED=1) is enqueued whole (no
+    host look) and returns before the device has finished; its results are those of the host-driven loop under the same
+    budget (bit for bit), the non-empty passes are counted on the device, and the call is ordered with the caller's stream."""
     import torch
+    monkeypatch.setenv("RMPC_NO_FUSED", "1")
     B = 192
     sc = rt["make_scenario"]("cfg4", B=B, seed=11)
     s = rt["Solver"](sc.desc, max_batch=B)

@@ -3,7 +3,7 @@
     python tests/tools/dev_vs_oracle.py cfg4 64 [seed]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle.oracle import Oracle
 from robot_mpcs_amd._lib import Solver
