@@ -219,6 +219,21 @@ __device__ __forceinline__ void sweep_part(const SweepK M, const V &v, const Swe
   auto symv = [](const double (&T)[6], const Vec3 &x) __attribute__((always_inline)) -> Vec3 {
     return {T[0] * x.x + T[1] * x.y + T[2] * x.z, T[1] * x.x + T[3] * x.y + T[4] * x.z, T[2] * x.x + T[4] * x.y + T[5] * x.z};
   };
+  // requests of the first distance row of every slot of this part (the usual case: one row per slot), all slots at once
+  struct FkRowIn { double tcv, lcv, gold, jo[NQ], op[4], wir; };
+  auto fk_row_load = [&](const int d, FkRowIn &in) __attribute__((always_inline)) {
+    const int i = d & 255, kind = (d >> 8) & 3, ob = (d >> 10) & 63, mod = (d >> 16) & 7, fi = (d >> 20) & 63;
+    in.tcv = tc[AIDX(i)]; in.lcv = lsrc[AIDXL(i)]; in.gold = gro[AIDX(i)];
+#pragma unroll
+    for (int a = 0; a < NQ; a++) in.jo[a] = jqo[AIDX(fi * NQ + a)];
+    const int obase = kind == ROW_LINEAR ? v.off_lin() + 4 * ob : (kind == ROW_RADIAL ? v.off_obst() + 4 * ob : 0);
+#pragma unroll
+    for (int c = 0; c < 4; c++) in.op[c] = PR(obase + c);
+    in.wir = PR(v.has_avoid() ? v.off_wconstr() + mod : 0);
+  };
+  FkRowIn fk0[NSP];
+#pragma unroll
+  for (int s = 0; s < NSP; s++) fk_row_load(sd0[s], fk0[s]);   // (a slot without rows: row 0's words, unused)
 #pragma unroll
   for (int s = 0; s < NSP; s++) {
     if (sv[s]) {
@@ -259,17 +274,15 @@ __device__ __forceinline__ void sweep_part(const SweepK M, const V &v, const Swe
         const int r = srb[s] + t;
         if (r < sre[s]) {
           const int d = t == 0 ? sd0[s] : v.fk_desc(r);
-          const int i = d & 255, kind = (d >> 8) & 3, ob = (d >> 10) & 63, mod = (d >> 16) & 7, fi = (d >> 20) & 63;
+          const int i = d & 255, kind = (d >> 8) & 3, fi = (d >> 20) & 63;
           const bool firstr = ((d >> 19) & 1) != 0;
-          // (every request of the row, then the arithmetic)
-          const double tcv = tc[AIDX(i)], lcv = lsrc[AIDXL(i)], gold = gro[AIDX(i)];
+          FkRowIn in = fk0[s];
+          if (t > 0) fk_row_load(d, in);   // (uniform: further rows of a slot)
+          const double tcv = in.tcv, lcv = in.lcv, gold = in.gold;
+          const double op0 = in.op[0], op1 = in.op[1], op2 = in.op[2], op3 = in.op[3], wir = in.wir;
           double jo[NQ];
 #pragma unroll
-          for (int a = 0; a < NQ; a++) jo[a] = jqo[AIDX(fi * NQ + a)];
-          const int obase = kind == ROW_LINEAR ? v.off_lin() + 4 * ob : (kind == ROW_RADIAL ? v.off_obst() + 4 * ob : 0);
-          const double op0 = PR(obase), op1 = PR(obase + 1), op2 = PR(obase + 2), op3 = PR(obase + 3);
-          const double wir = PR(v.has_avoid() ? v.off_wconstr() + mod : 0);
-          __builtin_amdgcn_sched_barrier(0);
+          for (int a = 0; a < NQ; a++) jo[a] = in.jo[a];
           const double wi = (v.has_avoid() && firstr) ? wir : 0.0;
           double gdz = 0.0;
 #pragma unroll
@@ -442,7 +455,7 @@ __device__ __forceinline__ void sweep_part(const SweepK M, const V &v, const Swe
           lcv[c][u] = lsrc[AIDXL(irow)];
           if ((du >> 11) & 1) plim[c][u] = pp[AIDX((int)((unsigned)d >> 16))];
           else plim[c][u] = v.v_val(jv[c], u);
-          wiv[c][u] = pp[AIDX(owc + ((d >> 12) & 7))];
+          wiv[c][u] = v.has_avoid() ? pp[AIDX(owc + ((d >> 12) & 7))] : 0.0;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -489,7 +502,9 @@ __device__ __forceinline__ void sweep_part(const SweepK M, const V &v, const Swe
           const double wi = (v.has_avoid() && firstr) ? wiv[c][u] : 0.0;
           const bool neutral = (k == 0) && (c < 2);   // constant of the problem at the pinned stage
           const double h = neutral ? 1.0 : sg * (z[c] - lim);
-          if (v.has_avoid()) {
+          // (inverse-barrier objective on the first row of a module: one joint's row at most -- skipped by a scalar
+          //  branch when no lane of the wavefront holds such a row with a non-zero weight)
+          if (v.has_avoid() && __ballot(firstr && wi != 0.0) != 0ull) {
             const bool on = (wi != 0.0) && !neutral;
             const double cN = (double)M.N * wi;
             bad |= (int)(on & !(h > 0.0));
