@@ -201,11 +201,20 @@ def kernel_report(prof, wall_ms, nsteps, B, d, iters_mean):
         alg = v["total_alg_bytes"] / v["launches"]   # pass kernels: bytes of the lanes still active, averaged (fill_lane_bytes)
         note = "pass kernel: algorithmic bytes of the lanes still iterating in each launch, averaged over the launches"
     achieved = alg / (avg_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch from the committed PMC passes -- only when they were collected with THIS library
+    # (profiles/pmc_traffic.json records the source hash of the library its passes ran; another library: null)
+    traffic, traffic_note = None, "no PMC passes committed for this configuration"
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get(d.get("_cfg", ""), {}).get(name)
+            tj = json.load(open(tfile))
+            meta = tj.get("_meta", {}).get(d.get("_cfg", ""), {})
+            if meta.get("library_source_hash") == d.get("_lib_hash"):
+                traffic = tj.get(d.get("_cfg", ""), {}).get(name)
+                traffic_note = meta.get("source", "")
+            else:
+                traffic_note = "profiles/pmc_traffic.json was collected with library %s, this run is library %s" % (
+                    meta.get("library_source_hash"), d.get("_lib_hash"))
         except Exception:
             traffic = None
     return {
@@ -213,7 +222,7 @@ def kernel_report(prof, wall_ms, nsteps, B, d, iters_mean):
         # 8(d)); `bound_by_counters`: what the PMC passes and the phase stamps under profiles/ say limits the kernel
         "kernel": name, "bound": "hbm", "bound_by_counters": BOUND_BY_COUNTERS.get(name, "latency"),
         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches": int(v["launches"]),
         "exclusive_leg": {"steps": nsteps, "wall_ms": wall_ms, "kernel_ms_sum": sum(p["total_ms"] for p in kern.values()),
                           "note": "one handle on one stream, HIP events around every kernel; kernel time <= wall time"},
@@ -333,7 +342,8 @@ def run_cfg5(args, fleet, dev, rank, world, dd, fence, steps, warmup, cdev=None)
     gc.enable()
     elapsed = fleet.max_over_ranks(time.perf_counter() - t0, dd, cdev or dev)
     ss = shard.steady_stats(reset=True)
-    st = np.array([np.concatenate([ss[k]["acc"], ss[k]["events"]]) for k in ("cfg2", "cfg3", "cfg4")]).ravel()
+    NST = 13   # acc (5) + events (4) + more (4) per fleet
+    st = np.array([np.concatenate([ss[k]["acc"], ss[k]["events"], ss[k]["more"]]) for k in ("cfg2", "cfg3", "cfg4")]).ravel()
     allst = fleet.gather_stats(st, dd, cdev or dev)
     shard.close()
     if rank != 0:
@@ -342,18 +352,30 @@ def run_cfg5(args, fleet, dev, rank, world, dd, fence, steps, warmup, cdev=None)
     total = 8192 * world
     per = {}
     for i, k in enumerate(("cfg2", "cfg3", "cfg4")):
-        a = allst[:, 8 * i: 8 * i + 8].sum(axis=0)
+        a = allst[:, NST * i: NST * i + NST].sum(axis=0)
         n = counts[k] * world * steps
+        handovers = max(1.0, a[10])
         per[k] = {"instances_per_gpu": counts[k], "usable_share": float((a[0] + a[1]) / n),
                   "cut_by_deadline_or_iteration_cap_per_step": float(a[2] / steps), "failed_per_step": float(a[3] / steps),
-                  "iters_mean": float(a[4] / n), "arrivals_per_step": float(a[5] / steps),
-                  "dwell_timeouts_per_step": float(a[6] / steps), "resets_per_step": float(a[7] / steps)}
+                  "iters_mean": float(a[4] / n),
+                  # goal hand-overs per control step: within the arrival tolerance / come to rest at the objective's
+                  # equilibrium (the reference's N w / h term keeps a robot off a goal next to an obstacle) / dwell time-out
+                  "arrivals_per_step": float(a[5] / steps), "settled_per_step": float(a[6] / steps),
+                  "dwell_timeouts_per_step": float(a[7] / steps),
+                  "mean_distance_to_goal_at_handover_m": float(a[9] / handovers),
+                  # a failed solve keeps its state and drives on (mpcPlanner.py:263-264); a reset (back to the start state)
+                  # only after %d failed control steps in a row
+                  "resets_per_step": float(a[8] / steps), "reset_share_per_step": float(a[8] / n),
+                  "share_of_instance_steps_inside_a_run_of_failed_solves": float(a[11] / n),
+                  "resets_because_out_of_workspace_per_step": float(a[12] / steps)}
     return dict(value=total * steps / elapsed, ms_per_step=1e3 * elapsed / steps, steps=steps,
                 config={"workload": WORKLOADS["cfg5"], "instances_per_gpu": 8192, "max_iter": args.max_iter,
                         "acc_iters": args.acc_iters, "pass_budget": args.pass_budget,
                         "pass_budget_boxer": args.pass_budget_boxer or args.pass_budget,
                         "pass_budget_arm": args.pass_budget_arm or args.pass_budget,
-                        "loop": "steady: new goal on arrival (or after %d control steps), start state after a failed solve; no episodes" % args.max_dwell,
+                        "loop": ("steady: new goal on arrival, on coming to rest or after %d control steps; a failed solve keeps its state "
+                                 "(reset to the start state after %d failures in a row); the boxers' obstacles move every control step; "
+                                 "no episodes" % (args.max_dwell, fleet.MixedFleetShard.FAIL_RESET_AFTER)),
                         "warm_start": "shifted plan + multipliers (rmpc_set_warm_start)",
                         "parallelism": f"{world} x per-robot-type blocks (fleet.partition_mixed), no data-path collective"},
                 loop={"rate_hz": float(steps / elapsed), "ms_p50": float(np.percentile(times, 50)),
@@ -367,13 +389,11 @@ def self_launch(args):
     (``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...``) as a child process, BEFORE this process
     has touched a GPU, and leave with the child's exit code.  A plain run must never report ``n_gpus: 1`` for
     ``--gpus 8``."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # (--standalone: the launcher's own c10d rendezvous on a free local port -- no port picked here and lost to
+    #  another job between bind and launch)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
@@ -393,7 +413,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: a launcher line must carry --gpus N "
+                         f"(python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)")
     if not torch.cuda.is_available():
         # No HIP device: there is no CPU fallback.  Under a multi-rank launch the rendezvous and the rank / argument
         # plumbing are still exercised (gloo), so that a launch line can be checked on a CPU box; the exit is non-zero.
@@ -438,10 +459,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # which device this rank drives (an N-rank line must show N distinct devices)
+    props = torch.cuda.get_device_properties(dev)
+    ident = "%s %s pci %s" % (props.name, getattr(props, "gcnArchName", "?"), getattr(props, "pci_bus_id", "?"))
+    if hasattr(props, "uuid"):
+        ident += " uuid %s" % props.uuid
+    if world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+    else:
+        idents = [ident]
     cfg = args.config
     base = {"metric": METRIC, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "library_source_hash": _lib.source_hash()}
+            "library_source_hash": _lib.source_hash(), "devices": idents}
     if rehearse:
         base["rehearsal"] = "%d ranks share GPU 0, collectives over gloo: launch plumbing only, NOT a multi-GPU measurement" % world
 
@@ -494,7 +525,7 @@ def main():
             ef, it, kk = lo.stats()
             st = fleet.summarize(fleet.gather_stats(fleet.solve_stats(ef, it, kk), dd, cdev), lo.B)
             lat, wall, pr = lo.exclusive(4) if not args.no_kernel_events else (None, None, None)
-            d2 = dict(lo.d, _cfg=other)
+            d2 = dict(lo.d, _cfg=other, _lib_hash=_lib.source_hash())
             legs[other] = {"workload": WORKLOADS[other], "value": lo.B * world * k / el, "unit": "solves/s", "steps": k,
                            "ms_per_step": 1e3 * el / k, "batch_latency_ms": lat,
                            "value_single_call": (lo.B * world / (lat * 1e-3)) if lat else None, "solve_stats": st,
@@ -508,7 +539,7 @@ def main():
         cfg5_extra = run_cfg5(args, fleet, dev, rank, world, dd, fence, args.cfg5_steps, 10)
 
     if rank == 0:
-        d = dict(leg.d, _cfg=cfg)
+        d = dict(leg.d, _cfg=cfg, _lib_hash=_lib.source_hash())
         stats = fleet.summarize(allstats, B)
         value = B * world * args.steps / elapsed_max
         out = dict(base, value=value, ms_per_step=1e3 * elapsed_max / args.steps, batch_latency_ms=latency_ms,
@@ -516,6 +547,7 @@ def main():
                    # definition, B / wall time of ONE call alone on the GPU (mean over the input sets), per GPU x world
                    value_single_call=(B * world / (latency_ms * 1e-3)) if latency_ms else None,
                    single_call_ms=getattr(leg, "single_call_ms", None),
+                   single_call_ms_median=(float(np.median(leg.single_call_ms)) if getattr(leg, "single_call_ms", None) else None),
                    value_note=("value: %d solver handles on %d streams take the steps round robin (launches overlap); "
                                "value_single_call: one rmpc_solve_batch_device at a time" % (S, S)),
                    config={"workload": WORKLOADS[cfg], "batch_per_gpu": B, "horizon": leg.N, "nvar": leg.nv,

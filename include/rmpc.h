@@ -41,7 +41,12 @@
 extern "C" {
 #endif
 
-#define RMPC_VERSION 104 /* 0.1.4: rmpc_set_pass_budget; curvature terms of the arms */
+/* 0.1.4 (104): rmpc_set_pass_budget; curvature terms of the arms.
+ * 0.1.5 (105): rmpc_is_async, rmpc_retarget_device (round 3; the macro was not bumped then).
+ * 0.2.0 (200): rmpc_retarget_device takes an rmpc_retarget struct (failed solves keep their state, settled robots,
+ *              64-bit counters: NOT source compatible with 0.1.5), rmpc_advance_obstacles_device; rmpc_is_fused is 1
+ *              for the arms with 5 .. 7 joints as well (k_fused_arm). */
+#define RMPC_VERSION 200
 
 #define RMPC_MAX_JOINTS 8
 #define RMPC_MAX_LINKS 8
@@ -239,19 +244,48 @@ int rmpc_advance_device_flags(rmpc_handle *h, int B, const double *d_z_prev, con
 
 /* Steady closed loop (fleet harness; the examples of the reference hand the planner its next goal whenever the driver
  * has one -- setGoalReaching every control step with the next waypoint, examples/boxer_example_global.py:203-212).
- * Called after rmpc_advance_device_flags: an instance whose end link has arrived within `tol` of its goal, or has
- * spent `max_dwell` control steps on it (0: no limit), takes the next goal of its pool d_goal_pool [B][pool_len][3]
- * (cursor d_cursor [B], dwell counter d_dwell [B], both int32 on the device, zero-initialised by the caller); an
- * instance whose solve FAILED (exitflag < 0) is put back to its start state d_x_start [B][nx] with a cold plan and takes
- * its next goal as well.  mu_regoal > 0 (with rmpc_set_warm_start(1)): the next solve of an instance that has just taken
- * a new goal keeps its multipliers but restarts its barrier parameter from mu_regoal (a new goal moves the optimum;
- * 1000 x the converged barrier parameter is too small a neighbourhood for it); 0: plain warm start.
- * d_goal [B][3] is the array the scene (rmpc_scene.goal) points at.  d_counts (may be NULL):
- * eight int32 counters, incremented: arrivals, dwell time-outs, resets, then the control step's exit flags (1, 2, 0,
- * < 0) and the sum of d_iters (may be NULL) -- loop statistics without a host read per control step. */
-int rmpc_retarget_device(rmpc_handle *h, int B, double *d_xinit, double *d_x0, const int32_t *d_exitflag, double *d_goal,
-                         const double *d_goal_pool, int pool_len, int32_t *d_cursor, int32_t *d_dwell, const double *d_x_start,
-                         double tol, int max_dwell, double mu_regoal, int32_t *d_counts, const int32_t *d_iters, void *stream);
+ * Called after rmpc_advance_device_flags, once per control step.  Every pointer is a DEVICE pointer.
+ *  - an instance whose end link is within `tol` of its goal has ARRIVED; one that has come to rest (largest joint /
+ *    wheel speed below settle_vel after at least settle_min_dwell control steps on this goal; settle_vel = 0: off) has
+ *    SETTLED -- with the reference's objective (N w / h on the first row of a module, constraint_avoidance.py:22-31) a
+ *    goal next to an obstacle is an equilibrium at a distance, not a point that is reached; one that has spent
+ *    max_dwell control steps on its goal (0: no limit) has TIMED OUT.  All three take the next goal of their pool
+ *    goal_pool [B][pool_len][3] (cursor [B], dwell [B]: int32, zero-initialised by the caller).
+ *  - an instance whose solve FAILED (exitflag < 0) keeps its state: the reference prints the flag and applies the action
+ *    it got (mpcPlanner.py:263-264), the next solve starts cold from the new state (rmpc_advance_device_flags =
+ *    examples/boxer_example.py:194-198).  Only after fail_reset_after failed control steps IN A ROW (failrun [B], int32,
+ *    zero-initialised; 0: never) is it put back to x_start [B][nx] with a cold plan and its next goal: a RESET.  The same
+ *    happens at once to an instance whose configuration has left the joint-limit box lower_limits / upper_limits [B][n]
+ *    (may be NULL: no check) by more than 5 % of its width: the plant of the loop is the bare integrator, the examples'
+ *    simulator would have stopped the joint at its limit (counted in counts[12] as well).
+ *  - mu_regoal > 0 (with rmpc_set_warm_start(1)): the next solve of an instance that has just taken a new goal keeps its
+ *    multipliers but restarts its barrier parameter from mu_regoal; 0: plain warm start.
+ *  - goal [B][3] is the array the scene (rmpc_scene.goal) points at.
+ *  - counts (may be NULL): twelve int64 counters, incremented: [0] arrivals, [1] settled, [2] time-outs, [3] resets,
+ *    [4..7] the control step's exit flags (1, 2, 0, < 0), [8] sum of iters (may be NULL), [9] sum of the distance to the
+ *    goal at the hand-overs in micrometres, [10] hand-overs counted in [9], [11] instances inside a run of failed
+ *    solves this step, [12] resets because the robot had left its workspace, [13..15] reserved -- loop statistics
+ *    without a host read per control step (64-bit: a loop may run for days). */
+typedef struct rmpc_retarget {
+  int32_t struct_size;            /* sizeof(rmpc_retarget) */
+  int32_t pool_len;
+  double *xinit, *x0;             /* [B][nx], [B][N][nvar] */
+  const int32_t *exitflag, *iters;
+  double *goal;
+  const double *goal_pool, *x_start;
+  const double *lower_limits, *upper_limits;
+  int32_t *cursor, *dwell, *failrun;
+  double tol, settle_vel, mu_regoal;
+  int32_t settle_min_dwell, max_dwell, fail_reset_after, reserved;
+  int64_t *counts;
+} rmpc_retarget;
+int rmpc_retarget_device(rmpc_handle *h, int B, const rmpc_retarget *r, void *stream);
+
+/* The moving obstacles between two control steps (what the examples' simulator does before the driver hands the planner
+ * ob[nx:], mpcPlanner.py:243-244): d_obst_dyn [B][nobst][9] = position, velocity, acceleration (rmpc_scene.obst_dyn):
+ * pos += vel dt + acc dt^2 / 2, vel += acc dt.  arena > 0: an obstacle that leaves [-arena, arena] in x or y comes back
+ * with that velocity component mirrored.  Needs no handle. */
+int rmpc_advance_obstacles_device(int B, int nobst, double dt, double arena, double *d_obst_dyn, void *stream);
 
 /* Free-space decomposition on the device: for each of the B*N seed points
  * (e.g. the planned lidar position of instance b at stage k) at most K half-planes

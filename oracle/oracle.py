@@ -55,6 +55,8 @@ class OrcStats(C.Structure):
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("RMPC_ORACLE_LIB"):   # (a build of the restatement made elsewhere: the sanitizer build, `make asan`)
+        return os.environ["RMPC_ORACLE_LIB"]
     src = os.path.join(_HERE, "rmpc_oracle.c")
     hdr = os.path.join(_HERE, "rmpc_oracle.h")
     stale = (not os.path.exists(_LIB_PATH)) or any(
@@ -71,8 +73,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(build())
         dp = C.POINTER(C.c_double)
         L.orc_desc_size.restype = C.c_int
         L.orc_eval_stage.restype = C.c_int

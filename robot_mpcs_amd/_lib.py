@@ -67,12 +67,24 @@ class RmpcScene(C.Structure):
     ]
 
 
+class RetargetArgs(C.Structure):
+    """Mirror of ``rmpc_retarget`` (include/rmpc.h): the steady loop's goal hand-over, device pointers."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("pool_len", C.c_int32),
+        ("xinit", C.c_void_p), ("x0", C.c_void_p), ("exitflag", C.c_void_p), ("iters", C.c_void_p), ("goal", C.c_void_p),
+        ("goal_pool", C.c_void_p), ("x_start", C.c_void_p), ("lower_limits", C.c_void_p), ("upper_limits", C.c_void_p), ("cursor", C.c_void_p), ("dwell", C.c_void_p), ("failrun", C.c_void_p),
+        ("tol", C.c_double), ("settle_vel", C.c_double), ("mu_regoal", C.c_double),
+        ("settle_min_dwell", C.c_int32), ("max_dwell", C.c_int32), ("fail_reset_after", C.c_int32), ("reserved", C.c_int32),
+        ("counts", C.c_void_p),
+    ]
+
+
 # every symbol include/rmpc.h declares
 EXPORTED_SYMBOLS = [
     "rmpc_version", "rmpc_source_hash", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
     "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_warm_start", "rmpc_set_pass_budget", "rmpc_is_fused", "rmpc_is_async", "rmpc_set_profiling", "rmpc_get_profile",
     "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep", "rmpc_spec_source", "rmpc_spec_name", "rmpc_spec_for", "rmpc_debug_poison_lds",
-    "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_pack_scene_workspace", "rmpc_solve_batch_packed_device", "rmpc_advance_device", "rmpc_advance_device_flags", "rmpc_retarget_device", "rmpc_free_space_device",
+    "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_pack_scene_workspace", "rmpc_solve_batch_packed_device", "rmpc_advance_device", "rmpc_advance_device_flags", "rmpc_retarget_device", "rmpc_advance_obstacles_device", "rmpc_free_space_device",
 ]
 
 _lib = None
@@ -190,7 +202,9 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_advance_device_flags.restype = C.c_int
     L.rmpc_advance_device_flags.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.rmpc_retarget_device.restype = C.c_int
-    L.rmpc_retarget_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + [C.c_double, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rmpc_retarget_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(RetargetArgs), C.c_void_p]
+    L.rmpc_advance_obstacles_device.restype = C.c_int
+    L.rmpc_advance_obstacles_device.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     L.rmpc_free_space_device.restype = C.c_int
     L.rmpc_free_space_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     if L.rmpc_desc_size() != C.sizeof(RmpcDesc):
@@ -404,14 +418,32 @@ class Solver:
         self._check(rc, "rmpc_advance_device_flags")
 
     def retarget_device(self, B, xinit, x0, exitflag, goal, goal_pool, cursor, dwell, x_start, tol, max_dwell=0, counts=None,
-                        iters=None, mu_regoal=0.0, stream=None):
-        """Steady closed loop (``rmpc_retarget_device``): next goal from the instance's pool on arrival / dwell time-out,
-        reset to the start state (and next goal) after a failed solve.  All arguments are device tensors."""
+                        iters=None, mu_regoal=0.0, stream=None, failrun=None, fail_reset_after=0, settle_vel=0.0,
+                        settle_min_dwell=0, lower_limits=None, upper_limits=None):
+        """Steady closed loop (``rmpc_retarget_device``): next goal from the instance's pool on arrival / coming to rest /
+        dwell time-out; a failed solve keeps its state (reset to the start state only after ``fail_reset_after`` failed
+        control steps in a row, or at once when it has left the joint-limit box).  All arrays are device tensors;
+        ``counts``: int64 [16]."""
         st = _stream_arg(stream)
-        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-        rc = self._L.rmpc_retarget_device(self._h, int(B), p(xinit), p(x0), p(exitflag), p(goal), p(goal_pool), int(goal_pool.shape[1]),
-                                          p(cursor), p(dwell), p(x_start), float(tol), int(max_dwell), float(mu_regoal), p(counts), p(iters), st)
+        p = lambda t: t.data_ptr() if t is not None else None
+        a = RetargetArgs()
+        a.struct_size = C.sizeof(RetargetArgs)
+        a.pool_len = int(goal_pool.shape[1])
+        a.xinit, a.x0, a.exitflag, a.iters, a.goal = p(xinit), p(x0), p(exitflag), p(iters), p(goal)
+        a.goal_pool, a.x_start, a.cursor, a.dwell, a.failrun = p(goal_pool), p(x_start), p(cursor), p(dwell), p(failrun)
+        a.lower_limits, a.upper_limits = p(lower_limits), p(upper_limits)
+        a.tol, a.settle_vel, a.mu_regoal = float(tol), float(settle_vel), float(mu_regoal)
+        a.settle_min_dwell, a.max_dwell, a.fail_reset_after, a.reserved = int(settle_min_dwell), int(max_dwell), int(fail_reset_after), 0
+        a.counts = p(counts)
+        rc = self._L.rmpc_retarget_device(self._h, int(B), C.byref(a), st)
         self._check(rc, "rmpc_retarget_device")
+
+    def advance_obstacles_device(self, obst_dyn, dt: float, arena: float = 0.0, stream=None):
+        """``rmpc_advance_obstacles_device``: the moving obstacles [B, nobst, 9] one control step on (device tensor)."""
+        st = _stream_arg(stream)
+        B, nobst = int(obst_dyn.shape[0]), int(obst_dyn.numel() // (9 * obst_dyn.shape[0]))
+        rc = self._L.rmpc_advance_obstacles_device(B, nobst, float(dt), float(arena), C.c_void_p(obst_dyn.data_ptr()), st)
+        self._check(rc, "rmpc_advance_obstacles_device")
 
     def set_warm_start(self, enable: bool):
         """Closed loops: start every solve from the multipliers of the previous solve of the same batch

@@ -4310,59 +4310,129 @@ __global__ __launch_bounds__(256) void k_advance(const DevModel M, const double 
 // arrived (within tol of the goal) or has dwelt max_dwell control steps on this goal; an instance whose solve FAILED
 // (exitflag < 0: infeasible or diverged, a state no plan leads out of) is put back to its start state with a cold
 // plan and takes its next goal too.  The goals live in the scene's goal array, so the next parameter packing sees them.
+struct RetargetDev {   // rmpc_retarget, device side
+  double *xinit, *x0, *goal;
+  const int *exitflag, *iters;
+  const double *pool, *x_start, *lower, *upper;
+  int P;
+  int *cursor, *dwell, *failrun;
+  double tol, settle_vel;
+  int settle_min_dwell, max_dwell, fail_reset_after;
+  long long *counts;
+  double *wmu;
+  double wmu_regoal;
+};
 template <class C>
-__global__ __launch_bounds__(256) void k_retarget(const DevModel M, const DevTables *__restrict__ Tp, int B, double *__restrict__ xinit,
-                                                  double *__restrict__ x0, const int *__restrict__ exitflag, double *__restrict__ goal,
-                                                  const double *__restrict__ pool, int P, int *__restrict__ cursor, int *__restrict__ dwell,
-                                                  const double *__restrict__ x_start, double tol, int max_dwell, int *__restrict__ counts,
-                                                  const int *__restrict__ iters, double *__restrict__ wmu, double wmu_regoal) {
+__global__ __launch_bounds__(256) void k_retarget(const DevModel M, const DevTables *__restrict__ Tp, int B, const RetargetDev R) {
   constexpr int NQ = C::NQ, NX = C::NX, NV = C::NV;
   const int b = blockIdx.x * 256 + threadIdx.x;
   const bool in = b < B;
+  long long *const counts = R.counts;
   // statistics of the control step, summed on the device (no host read inside the loop): exit flags and iterations
-  if (counts && exitflag) {
-    const int ef = in ? exitflag[b] : -1000;
-    const int it = (in && iters) ? iters[b] : 0;
+  if (counts && R.exitflag) {
+    const int ef = in ? R.exitflag[b] : -1000;
+    const int it = (in && R.iters) ? R.iters[b] : 0;
     const int cls[4] = {ef == 1, ef == 2, ef == 0, ef < 0 && ef > -1000};
     for (int c = 0; c < 4; c++) {
       const unsigned long long mk = __ballot(cls[c]);
-      if ((threadIdx.x & 63) == 0 && mk) atomicAdd(&counts[3 + c], __popcll(mk));
+      if ((threadIdx.x & 63) == 0 && mk) atomicAdd((unsigned long long *)&counts[4 + c], (unsigned long long)__popcll(mk));
     }
     int si = it;
     for (int off = 32; off >= 1; off >>= 1) si += __shfl_xor(si, off, 64);
-    if ((threadIdx.x & 63) == 0 && si) atomicAdd(&counts[7], si);
+    if ((threadIdx.x & 63) == 0 && si) atomicAdd((unsigned long long *)&counts[8], (unsigned long long)si);
   }
   if (!in) return;
   const RtView v(M, *Tp);
-  const bool failed = exitflag && exitflag[b] < 0;
-  if (failed) {
-    for (int j = 0; j < NX; j++) xinit[(size_t)b * NX + j] = x_start[(size_t)b * NX + j];
-    for (int k = 0; k < M.N; k++)
-      for (int j = 0; j < NV; j++) x0[((size_t)b * M.N + k) * NV + j] = j < NX ? x_start[(size_t)b * NX + j] : 0.0;
+  double *const xi = R.xinit + (size_t)b * NX;
+  const bool failed = R.exitflag && R.exitflag[b] < 0;
+  // A failed solve (infeasible, diverged, line search): the reference prints the flag and drives on with the action it
+  // got (mpcPlanner.py:263-264), its boxer example takes the current pose as the next linearisation point
+  // (boxer_example.py:194-198) -- the plant step has applied the returned control, the next solve starts cold from the
+  // new state (rmpc_advance_device_flags).  Only an instance that has failed fail_reset_after control steps IN A ROW is
+  // put back to its start state (a reset; 0: never).
+  int fr = R.failrun ? R.failrun[b] : 0;
+  fr = failed ? fr + 1 : 0;
+  // ... or one whose configuration has left the joint-limit box by more than a limit row's reach (a robot outside its
+  // workspace: the examples' simulator stops a joint at its limit, the plant here is the bare integrator -- a short
+  // horizon without a terminal set does overshoot a far goal; counted on its own, counts[12])
+  bool oob = false;
+  if (R.lower && R.upper) {
+    for (int j = 0; j < M.n; j++) {
+      const double lo = R.lower[(size_t)b * M.n + j], hi = R.upper[(size_t)b * M.n + j];
+      const double margin = 0.05 * (hi - lo);
+      oob |= (xi[j] < lo - margin) | (xi[j] > hi + margin);
+    }
   }
+  const bool reset = oob || (failed && R.fail_reset_after > 0 && fr >= R.fail_reset_after);
+  if (counts && oob) atomicAdd((unsigned long long *)&counts[12], 1ull);
+  if (reset) {
+    for (int j = 0; j < NX; j++) xi[j] = R.x_start[(size_t)b * NX + j];
+    for (int k = 0; k < M.N; k++)
+      for (int j = 0; j < NV; j++) R.x0[((size_t)b * M.N + k) * NV + j] = j < NX ? R.x_start[(size_t)b * NX + j] : 0.0;
+    fr = 0;
+  }
+  if (R.failrun) R.failrun[b] = fr;
+  if (counts && fr > 0) atomicAdd((unsigned long long *)&counts[11], 1ull);
   double q[NQ];
 #pragma unroll
-  for (int j = 0; j < NQ; j++) q[j] = xinit[(size_t)b * NX + j];
+  for (int j = 0; j < NQ; j++) q[j] = xi[j];
   Kin<C> kin;
   kin.compute(v, q);
   Vec3 J[NQ];
   const Vec3 pt = kin.template point<0>(v, J);   // slot 0: the goal's end frame (build_tables)
-  const double dx = pt.x - goal[(size_t)b * 3], dy = pt.y - goal[(size_t)b * 3 + 1], dz = pt.z - goal[(size_t)b * 3 + 2];
-  const bool arrived = sqrt(dx * dx + dy * dy + dz * dz) < tol;
-  int dw = dwell[b] + 1;
-  const bool late = max_dwell > 0 && dw >= max_dwell;
-  if (arrived || late || failed) {
-    const int c = cursor[b] + 1;
-    cursor[b] = c;
-    const double *g = pool + ((size_t)b * P + (size_t)(c % P)) * 3;
-    goal[(size_t)b * 3] = g[0]; goal[(size_t)b * 3 + 1] = g[1]; goal[(size_t)b * 3 + 2] = g[2];
+  double *const g = R.goal + (size_t)b * 3;
+  const double dx = pt.x - g[0], dy = pt.y - g[1], dz = pt.z - g[2];
+  const double dist = sqrt(dx * dx + dy * dy + dz * dz);
+  const bool arrived = dist < R.tol;
+  // settled: the robot has come to rest on this goal -- with the reference's objective (N w / h on the first row of a
+  // module, constraint_avoidance.py:22-31) a goal next to an obstacle is an equilibrium at a distance, not a point reached
+  double vmax = 0.0;
+  if constexpr (C::ROBOT == RMPC_ROBOT_CHAIN) {
+#pragma unroll
+    for (int j = 0; j < NQ; j++) vmax = fmax(vmax, fabs(xi[NQ + j]));
+  } else {
+    vmax = fmax(fabs(xi[6]), fabs(xi[7]));
+  }
+  int dw = R.dwell[b] + 1;
+  const bool settled = !arrived && R.settle_vel > 0.0 && dw >= R.settle_min_dwell && vmax < R.settle_vel;
+  const bool late = R.max_dwell > 0 && dw >= R.max_dwell;
+  if (arrived || settled || late || reset) {
+    const int c = R.cursor[b] + 1;
+    R.cursor[b] = c;
+    const double *gn = R.pool + ((size_t)b * R.P + (size_t)(c % R.P)) * 3;
+    g[0] = gn[0]; g[1] = gn[1]; g[2] = gn[2];
     dw = 0;
     // a new goal moves the optimum: the multipliers of the last solve stay, the barrier parameter of the next solve
     // restarts from mu_regoal (stored so that warm_mu() yields it) instead of 1000 x the converged one
-    if (wmu && wmu_regoal > 0.0 && !failed) wmu[b] = wmu_regoal;
-    if (counts) atomicAdd(&counts[failed ? 2 : (arrived ? 0 : 1)], 1);
+    if (R.wmu && R.wmu_regoal > 0.0 && !failed) R.wmu[b] = R.wmu_regoal;
+    if (counts) {
+      atomicAdd((unsigned long long *)&counts[reset ? 3 : (arrived ? 0 : (settled ? 1 : 2))], 1ull);
+      if (!reset) {
+        atomicAdd((unsigned long long *)&counts[9], (unsigned long long)(dist * 1e6));   // distance at the hand-over [um]
+        atomicAdd((unsigned long long *)&counts[10], 1ull);
+      }
+    }
   }
-  dwell[b] = dw;
+  R.dwell[b] = dw;
+}
+
+// The environment of the moving obstacles between two control steps (what the examples' simulator does before the driver
+// hands the planner ob[nx:], mpcPlanner.py:243-244): pos += vel dt + acc dt^2 / 2, vel += acc dt, one lane per
+// (instance, obstacle); arena > 0: an obstacle that leaves [-arena, arena] in x or y comes back (velocity component
+// mirrored), so that a loop that runs for hours keeps its obstacles.
+static __global__ __launch_bounds__(256) void k_obst_advance(double *__restrict__ od, int n, double dt, double arena) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double *o = od + (size_t)i * 9;
+  for (int c = 0; c < 3; c++) {
+    double pos = o[c] + o[3 + c] * dt + 0.5 * o[6 + c] * dt * dt;
+    double vel = o[3 + c] + o[6 + c] * dt;
+    if (arena > 0.0 && c < 2) {
+      if (pos > arena) { pos = 2.0 * arena - pos; vel = -vel; }
+      else if (pos < -arena) { pos = -2.0 * arena - pos; vel = -vel; }
+    }
+    o[c] = pos; o[3 + c] = vel;
+  }
 }
 
 // Launch order of a COLD fused launch that is larger than the chip (more instances than half-wavefronts: the rest wait
@@ -4663,11 +4733,8 @@ int launch_advance(rmpc_handle *h, int B, const double *d_z_prev, const int *ef,
   return 0;
 }
 template <class C>
-int launch_retarget(rmpc_handle *h, int B, double *d_xinit, double *d_x0, const int *ef, double *d_goal, const double *d_goal_pool,
-                    int pool_len, int *d_cursor, int *d_dwell, const double *d_x_start, double tol, int max_dwell, int *d_counts,
-                    const int *d_iters, double *wmu, double wmu_regoal, hipStream_t st) {
-  hipLaunchKernelGGL((k_retarget<C>), dim3((B + 255) / 256), dim3(256), 0, st, h->M, h->d_T, B, d_xinit, d_x0, ef, d_goal, d_goal_pool,
-                     pool_len, d_cursor, d_dwell, d_x_start, tol, max_dwell, d_counts, d_iters, wmu, wmu_regoal);
+int launch_retarget(rmpc_handle *h, int B, const RetargetDev &R, hipStream_t st) {
+  hipLaunchKernelGGL((k_retarget<C>), dim3((B + 255) / 256), dim3(256), 0, st, h->M, h->d_T, B, R);
   return 0;
 }
 
@@ -4678,7 +4745,7 @@ int launch_retarget(rmpc_handle *h, int B, double *d_xinit, double *d_x0, const 
 #define RMPC_SIG_PASS (rmpc_handle *, const Phase &, int, int, hipStream_t, int)
 #define RMPC_SIG_FUSED (rmpc_handle *, int, const double *, const double *, const double *, double *, int *, int *, double *, double *, hipStream_t, int)
 #define RMPC_SIG_ADV (rmpc_handle *, int, const double *, const int *, double *, double *, int, hipStream_t)
-#define RMPC_SIG_RET (rmpc_handle *, int, double *, double *, const int *, double *, const double *, int, int *, int *, const double *, double, int, int *, const int *, double *, double, hipStream_t)
+#define RMPC_SIG_RET (rmpc_handle *, int, const RetargetDev &, hipStream_t)
 #define RMPC_INST(KW, R, NQ, NS)                                      \
   KW int launch_pass<Cfg<R, NQ, NS>, RtView> RMPC_SIG_PASS;           \
   KW int launch_advance<Cfg<R, NQ, NS>> RMPC_SIG_ADV;                 \
@@ -5753,26 +5820,37 @@ int rmpc_advance_device(rmpc_handle *h, int B, const double *d_z_prev, double *d
   return rmpc_advance_device_flags(h, B, d_z_prev, nullptr, d_xinit, d_x0, previous_plan, stream);
 }
 
-int rmpc_retarget_device(rmpc_handle *h, int B, double *d_xinit, double *d_x0, const int32_t *d_exitflag, double *d_goal,
-                         const double *d_goal_pool, int pool_len, int32_t *d_cursor, int32_t *d_dwell, const double *d_x_start,
-                         double tol, int max_dwell, double mu_regoal, int32_t *d_counts, const int32_t *d_iters, void *stream) {
-  if (!h || !d_xinit || !d_x0 || !d_goal || !d_goal_pool || !d_cursor || !d_dwell || !d_x_start) return fail("null argument");
+int rmpc_retarget_device(rmpc_handle *h, int B, const rmpc_retarget *r, void *stream) {
+  if (!h || !r) return fail("null argument");
+  if (r->struct_size != (int)sizeof(rmpc_retarget)) return fail("rmpc_retarget.struct_size mismatch");
+  if (!r->xinit || !r->x0 || !r->goal || !r->goal_pool || !r->cursor || !r->dwell || !r->x_start) return fail("null argument");
   if (B < 1 || B > h->max_batch) return fail("batch size out of range for this handle");
-  if (pool_len < 1) return fail("goal pool must hold at least one goal per instance");
+  if (r->pool_len < 1) return fail("goal pool must hold at least one goal per instance");
   if (!h->desc.has_goal) return fail("the model has no GoalReaching objective");
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
-  const int *ef = (const int *)d_exitflag;
-  double *const wmu = h->warm_mode ? (h->fused ? h->F.wmu : h->W.wmu) : nullptr;
-  const double wmu_regoal = mu_regoal > 0.0 ? mu_regoal / kWarmKappa : 0.0;
-#define RMPC_RT(ID, R, NQ, NS)                                                                                              \
-  if constexpr (variant_available<R, NQ, NS>()) {                                                                           \
-    if (h->variant == ID)                                                                                                   \
-      launch_retarget<Cfg<R, NQ, NS>>(h, B, d_xinit, d_x0, ef, d_goal, d_goal_pool, pool_len, (int *)d_cursor, (int *)d_dwell, \
-                                      d_x_start, tol, max_dwell, (int *)d_counts, (const int *)d_iters, wmu, wmu_regoal, st); \
+  RetargetDev R;
+  R.xinit = r->xinit; R.x0 = r->x0; R.goal = r->goal; R.exitflag = (const int *)r->exitflag; R.iters = (const int *)r->iters;
+  R.pool = r->goal_pool; R.x_start = r->x_start; R.P = r->pool_len; R.lower = r->lower_limits; R.upper = r->upper_limits;
+  R.cursor = (int *)r->cursor; R.dwell = (int *)r->dwell; R.failrun = (int *)r->failrun;
+  R.tol = r->tol; R.settle_vel = r->settle_vel; R.settle_min_dwell = r->settle_min_dwell; R.max_dwell = r->max_dwell;
+  R.fail_reset_after = r->fail_reset_after; R.counts = (long long *)r->counts;
+  R.wmu = h->warm_mode ? (h->fused ? h->F.wmu : h->W.wmu) : nullptr;
+  R.wmu_regoal = r->mu_regoal > 0.0 ? r->mu_regoal / kWarmKappa : 0.0;
+#define RMPC_RT(ID, R_, NQ, NS)                                                   \
+  if constexpr (variant_available<R_, NQ, NS>()) {                                \
+    if (h->variant == ID) launch_retarget<Cfg<R_, NQ, NS>>(h, B, R, st);          \
   }
   RMPC_VARIANTS(RMPC_RT)
 #undef RMPC_RT
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int rmpc_advance_obstacles_device(int B, int nobst, double dt, double arena, double *d_obst_dyn, void *stream) {
+  if (B < 1 || nobst < 1 || !d_obst_dyn) return fail("bad argument");
+  const int n = B * nobst;
+  hipLaunchKernelGGL(k_obst_advance, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_obst_dyn, n, dt, arena);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -101,6 +101,18 @@ class MixedFleetShard:
     # steady loop: arrival tolerance of the end link [m] and goals per instance
     ARRIVE_TOL = {"cfg2": 0.25, "cfg3": 0.35, "cfg4": 0.10}
     POOL = 16
+    # a robot that has come to rest on its goal has SETTLED (largest joint / wheel speed below this after SETTLE_MIN control
+    # steps on the goal): with the reference's objective -- N w / h on the first row of a module, as written in
+    # constraint_avoidance.py:22-31 -- a goal next to an obstacle is an equilibrium at a distance (an oracle closed loop of
+    # the panda example's scene comes to rest 0.19 .. 0.43 m from its goal with every solve converged: tests/tools/
+    # dev_oracle_arrival.py), not a point that is reached
+    SETTLE_VEL = {"cfg2": 0.02, "cfg3": 0.02, "cfg4": 0.03}
+    SETTLE_MIN = 20
+    # a failed solve keeps its state and drives on (mpcPlanner.py:263-264); only this many failed control steps in a row
+    # put an instance back to its start state
+    FAIL_RESET_AFTER = 25
+    # the moving obstacles of the boxers stay inside the arena [m] (they are mirrored at its walls)
+    ARENA = 9.0
     # barrier parameter the first solve after a goal hand-over restarts from (rmpc_retarget_device)
     MU_REGOAL = {"cfg2": 0.0, "cfg3": 1e-1, "cfg4": 0.0}
 
@@ -148,18 +160,20 @@ class MixedFleetShard:
             extra = {}
             if self.steady:
                 pool = goal_pool(name, sc, self.POOL, seed + 1000)
+                ten["goal"] = t(pool[:, 0])   # (the mobile robots' first goal is a local one too: goal_pool)
                 extra = dict(pool=t(pool), cursor=torch.zeros(B, dtype=torch.int32, device=device),
                              dwell=torch.zeros(B, dtype=torch.int32, device=device),
-                             # [arrivals, dwell time-outs, resets, converged, acceptable, cut (iteration cap / deadline),
-                             #  failed, iterations]: summed over the control steps by rmpc_retarget_device
-                             counts=torch.zeros(8, dtype=torch.int32, device=device))
+                             failrun=torch.zeros(B, dtype=torch.int32, device=device),
+                             # rmpc_retarget_device's counters (include/rmpc.h), summed over the control steps on the device
+                             counts=torch.zeros(16, dtype=torch.int64, device=device))
             self.fleets.append(dict(extra, 
                 name=name, B=B, s=s, sc=sc, scene=s.make_scene(sc.setup["mpc"]["weights"], **ten),
                 x=t(sc.xinit), x0=t(sc.x0), x_start=t(sc.xinit), x0_start=t(sc.x0),
                 z=torch.empty((B, N, nv), dtype=torch.float64, device=device),
                 ef=torch.empty(B, dtype=torch.int32, device=device), it=torch.empty(B, dtype=torch.int32, device=device),
                 kkt=torch.empty(B, dtype=torch.float64, device=device), obj=torch.empty(B, dtype=torch.float64, device=device),
-                goal=ten["goal"],
+                goal=ten["goal"], obst_dyn=ten.get("obst_dyn"), dt=float(d["dt"]),
+                lim_lo=ten["lower_limits"], lim_hi=ten["upper_limits"],
                 stream=torch.cuda.Stream(device=device)))   # (a higher dispatch priority for the arm's stream: no effect, measured twice)
         torch.cuda.synchronize(device)
 
@@ -178,7 +192,13 @@ class MixedFleetShard:
         if self.steady:
             f["s"].retarget_device(f["B"], f["x"], f["x0"], f["ef"], f["goal"], f["pool"], f["cursor"], f["dwell"], f["x_start"],
                                    self.ARRIVE_TOL[f["name"]], self.max_dwell, counts=f["counts"], iters=f["it"],
-                                   mu_regoal=self.mu_regoal[f["name"]], stream=st)
+                                   mu_regoal=self.mu_regoal[f["name"]], stream=st, failrun=f["failrun"],
+                                   fail_reset_after=self.FAIL_RESET_AFTER, settle_vel=self.SETTLE_VEL[f["name"]],
+                                   settle_min_dwell=self.SETTLE_MIN, lower_limits=f["lim_lo"], upper_limits=f["lim_hi"])
+            if f["obst_dyn"] is not None:
+                # the world moves on: the next control step's scene predicts from the obstacles' new state
+                # (updateDynamicObstacles(ob[nx:]), mpcPlanner.py:243-244,144-161)
+                f["s"].advance_obstacles_device(f["obst_dyn"], f["dt"], arena=self.ARENA, stream=st)
 
     def tick(self, sync: bool = True):
         """One control step of the whole shard.  A fused solve fills every SIMD with one long-lived wavefront, and a
@@ -231,14 +251,17 @@ class MixedFleetShard:
         return out
 
     def steady_stats(self, reset: bool = True):
-        """steady loop: per block [converged, acceptable, cut (iteration cap / deadline), failed, iterations] summed over
-        the control steps since the last call, and [arrivals, dwell time-outs, resets]; one host read per block"""
+        """steady loop, summed over the control steps since the last call (one host read per block):
+        ``acc`` = [converged, acceptable, cut (iteration cap / deadline), failed, iterations],
+        ``events`` = [arrivals, settled, dwell time-outs, resets],
+        ``more`` = [sum of the distance to the goal at the hand-overs (m), hand-overs, instance-steps inside a run of failed
+        solves, resets because the robot had left its workspace]"""
         out = {}
         cur = self.torch.cuda.current_stream(self.dev)
         for f in self.fleets:
             cur.wait_stream(f["stream"])
             c = f["counts"].cpu().numpy().astype(np.float64)
-            out[f["name"]] = dict(acc=c[3:8].copy(), events=c[:3].copy())
+            out[f["name"]] = dict(acc=c[4:9].copy(), events=c[:4].copy(), more=np.array([c[9] * 1e-6, c[10], c[11], c[12]]))
             if reset:
                 f["counts"].zero_()
                 f["stream"].wait_stream(cur)
@@ -250,11 +273,13 @@ class MixedFleetShard:
 
 
 def goal_pool(name: str, sc, P: int, seed: int):
-    """[B, P, 3] goals per instance for the steady loop; goal 0 is the scenario's.  The mobile robots get LOCAL goals, a
-    random walk of 2 .. 4 m steps (boxers 1.5 .. 3 m) inside the arena and clear of the instance's obstacles -- what the
-    reference's driver with a global planner hands the planner (the next waypoint of a path, get_local_goal,
-    examples/boxer_example_global.py:203-212), not a new task at the other end of the map; the arms get goals drawn
-    like the scenario's own."""
+    """[B, P, 3] goals per instance for the steady loop.  The mobile robots get LOCAL goals, a random walk of 2 .. 4 m steps
+    (boxers 1.5 .. 3 m) that starts at the robot's start position, inside the arena and clear of the instance's obstacles
+    -- what the reference's driver with a global planner hands the planner (the next waypoint of a path, get_local_goal,
+    examples/boxer_example_global.py:203-212), not a task at the other end of the map: the scenarios' own goals are up to
+    20 m away, and a 1.5 s horizon without a terminal set accelerates towards such a goal until it cannot stop in front of
+    the workspace limits any more (oracle closed loop: a third of the point robots beyond their joint limits after 100
+    control steps).  The arms get goals drawn like the scenario's own (goal 0 is the scenario's)."""
     rng = np.random.default_rng(seed)
     g0 = np.asarray(sc.extra["goal"], dtype=np.float64)
     B = g0.shape[0]
@@ -264,6 +289,7 @@ def goal_pool(name: str, sc, P: int, seed: int):
     if name == "cfg4":
         pool[:, 1:] = np.array([0.1, -0.6, 0.4]) + rng.uniform(-0.15, 0.15, size=(B, P - 1, 3))
         return pool
+    start = np.asarray(sc.xinit, dtype=np.float64)[:, :2]
     if "obst_dyn" in sc.extra:
         opos = sc.extra["obst_dyn"].reshape(B, -1, 9)[:, :, :2]
         clear = np.full(opos.shape[:2], 0.1 + r_body + 1.0)
@@ -272,14 +298,15 @@ def goal_pool(name: str, sc, P: int, seed: int):
         opos = sc.extra["obst_pos"][:, :, :2]
         clear = sc.extra["obst_radius"] + r_body + 0.2
         lim, step = 8.0, (2.0, 4.0)
-    for j in range(1, P):
+    for j in range(0, P):
         todo = np.ones(B, dtype=bool)
         while todo.any():
             idx = np.flatnonzero(todo)
             k = idx.size
             ang = rng.uniform(-np.pi, np.pi, size=k)
             ln = rng.uniform(step[0], step[1], size=k)
-            cand = pool[idx, j - 1, :2] + ln[:, None] * np.stack([np.cos(ang), np.sin(ang)], axis=1)
+            prev = start[idx] if j == 0 else pool[idx, j - 1, :2]
+            cand = prev + ln[:, None] * np.stack([np.cos(ang), np.sin(ang)], axis=1)
             ok = np.all(np.abs(cand) <= lim, axis=1)
             ok &= np.all(np.linalg.norm(cand[:, None, :] - opos[idx], axis=2) > clear[idx], axis=1)
             pool[idx[ok], j, :2] = cand[ok]
