@@ -129,9 +129,14 @@ static int fk_axes(const orc_desc *d, const double *q, int frame, double *pos, d
 int orc_fk_curv(const orc_desc *d, const double *q, int frame, const double *F, double *Cacc) {
   const int n = d->n;
   double pos[3], Jp[3 * 8], ax[8][3];
-  if (d->robot != ORC_ROBOT_CHAIN) return -2;
-  int rc = fk_axes(d, q, frame, pos, Jp, ax);
+  int rc = fk_axes(d, q, frame, pos, Jp, d->robot == ORC_ROBOT_CHAIN ? ax : 0);
   if (rc != 0) return rc;
+  if (d->robot == ORC_ROBOT_DIFFDRIVE) {
+    /* p = (x, y) + R(theta) o: only d2 p / dtheta2 = -(p - (x, y)) is non-zero (diff_drive_mpc_model.py: the frames ride
+     * on the base) */
+    Cacc[2 * n + 2] -= F[0] * (pos[0] - q[0]) + F[1] * (pos[1] - q[1]);
+    return 0;
+  }
   for (int a = 0; a < n; a++) {
     /* G = F x axis_a, then F . (axis_a x J_b) = G . J_b */
     const double G[3] = {F[1] * ax[a][2] - F[2] * ax[a][1], F[2] * ax[a][0] - F[0] * ax[a][2],
@@ -280,8 +285,17 @@ static __thread double tl_C[ORC_NH_MAX][64];   /* n x n curvature matrix per gen
 static __thread double tl_cw[ORC_NH_MAX];      /* extra weight from the inverse-barrier objective */
 static __thread double tl_G[64];               /* second-order term of the goal cost in q (models with_fk_curv) */
 
-/* models whose distance rows and goal cost carry second derivatives of the kinematics: the arms (n > 3) */
-static int with_fk_curv(const orc_desc *d) { return d->robot == ORC_ROBOT_CHAIN && d->ns == 0 && d->n > 3; }
+/* the arms (n > 3, no slack): exact second-order terms with the latch-release rule of round 2 */
+static int arm_curv(const orc_desc *d) { return d->robot == ORC_ROBOT_CHAIN && d->ns == 0 && d->n > 3; }
+/* the diff-drive base (round 4): exact second-order terms of the unicycle -- nu . grad^2 Phi of the discrete dynamics
+ * and the rotation of off-centre frames (ORC_DD_CURV=0 in the environment: Gauss-Newton blocks only, for A/B runs) */
+static int dd_curv(const orc_desc *d) {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("ORC_DD_CURV"); on = (e && e[0] == '0') ? 0 : 1; }
+  return d->robot == ORC_ROBOT_DIFFDRIVE && on;
+}
+/* models whose distance rows and goal cost carry second derivatives of the kinematics */
+static int with_fk_curv(const orc_desc *d) { return arm_curv(d) || dd_curv(d); }
 
 
 /* fixed_state != 0 (stage 1, whose state is pinned to xinit): rows that depend on the state
@@ -866,7 +880,35 @@ static int frame_is_affine(const orc_desc *d, int f) {
     if (d->joint_type[j] == ORC_JOINT_REVOLUTE && j != f) return 0;
   return 1;
 }
+/* nu . grad^2 Phi of the unicycle's discrete dynamics (ERK2, explicit midpoint, ORC_ERK_NODES nodes of h = dt / nodes:
+ * disc_dyn above).  In closed form the map is x+ = x + h sum_n cos(alpha_n) beta_n, y+ = y + h sum_n sin(alpha_n) beta_n
+ * with alpha_n = theta + a_n omega + b_n u1 (midpoint heading of node n), beta_n = v + a_n u0 (midpoint speed),
+ * a_n = (n + 1/2) h, b_n = h^2 n (n + 1) / 2; theta+, v+, omega+ are linear.  So only the costates of x and y carry
+ * curvature:  D = h sum_n [ (-nx cos - ny sin) beta_n ga ga^T + (-nx sin + ny cos) (ga gb^T + gb ga^T) ],
+ * ga = d alpha_n / d(theta, omega, u1) = (1, a_n, b_n), gb = d beta_n / d(v, u0) = (1, a_n).  Added to Q (nv x nv). */
+static void dd_dyn_curv(const orc_desc *d, const double *z, const double *nun, double *Q) {
+  const int nx = d->nx, nv = nvar_of(d), iu = nx + d->ns;
+  const double h = d->dt / ORC_ERK_NODES;
+  const double th = z[2], v = z[6], om = z[7], u0 = z[iu], u1 = z[iu + 1];
+  const int ia[3] = {2, 7, iu + 1}, ib[2] = {6, iu};
+  for (int n = 0; n < ORC_ERK_NODES; n++) {
+    const double an = (n + 0.5) * h, bn = h * h * n * (n + 1) * 0.5;
+    const double al = th + an * om + bn * u1, be = v + an * u0;
+    const double c = cos(al), s = sin(al);
+    const double P = h * (-nun[0] * c - nun[1] * s) * be, S = h * (-nun[0] * s + nun[1] * c);
+    const double ga[3] = {1.0, an, bn}, gb[2] = {1.0, an};
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) Q[ia[i] * nv + ia[j]] += P * ga[i] * ga[j];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 2; j++) {
+        Q[ia[i] * nv + ib[j]] += S * ga[i] * gb[j];
+        Q[ib[j] * nv + ia[i]] += S * ga[i] * gb[j];
+      }
+  }
+}
+
 static int model_uses_curvature(const orc_desc *d) {
+  if (dd_curv(d)) return 1;
   if (d->robot != ORC_ROBOT_CHAIN || d->ns != 0) return 0;
   if (with_fk_curv(d)) return 1;   /* the kinematics' own second derivatives are part of the terms */
   for (int mi = 0; mi < d->n_modules; mi++) {
@@ -926,6 +968,12 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
   int exitflag = 0, it = 0;
   const int curv_ok = model_uses_curvature(d);
   int gn_sticky = 0, curv_fail = 0, stall = 0;
+  /* (the unicycle) after a curvature step that failed -- exact Hessian not positive definite, or its two-trial line
+   * search -- the next curvature steps are skipped: 1, 2, 4 ... 16 iterations, the count doubling with every failure in
+   * a row and starting over after a success.  In a non-convex region every iteration would otherwise pay a failed
+   * factorisation or two failed trials plus a null pass before its Gauss-Newton step (one instance of the BASELINE
+   * batch: 99 iterations in 315 passes); a permanent latch (the arms' rule) would give up the quadratic end game. */
+  int curv_skip = 0, curv_back = 0;
   int ls_start = 0; /* step-length memory: halvings the next Gauss-Newton line search starts from */
   double obj_prev = 0.0;
   tl_passes = 1;
@@ -1017,6 +1065,7 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
     /* ---- step computation: exact constraint curvature first (when the model
      * qualifies and no fallback is latched), Gauss-Newton blocks otherwise ---- */
     int use_curv = curv_ok && !gn_sticky && mu <= ORC_CURV_MU;
+    if (use_curv && dd_curv(d) && curv_skip > 0) { curv_skip--; use_curv = 0; }
     double alpha = 0.0, ad = 1.0;
     int ls = 0, accepted = 0, fatal = 0;
     for (;;) {
@@ -1048,9 +1097,15 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
           for (int a2 = 0; a2 < d->n; a2++)
             for (int b2 = 0; b2 < d->n; b2++) Q[a2 * nv + b2] += G[a2 * d->n + b2];
         }
+        if (use_curv && dd_curv(d) && k < N - 1) dd_dyn_curv(d, w->z + (size_t)k * nv, w->nu + (size_t)(k + 1) * nx, Q);
       }
       if (riccati(w) != 0) {
-        if (use_curv) { use_curv = 0; tl_passes++; continue; } /* this iteration only */
+        if (use_curv) {
+          use_curv = 0;
+          tl_passes++;
+          if (dd_curv(d)) { curv_back = curv_back ? (curv_back < 16 ? 2 * curv_back : 16) : 1; curv_skip = curv_back; }
+          continue; /* this iteration only */
+        }
         fatal = 1;
         break;
       }
@@ -1097,16 +1152,17 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
         alpha *= 0.5;
       }
       if (!accepted && use_curv) {
-        /* Gauss-Newton fallback for this iteration; latched after repeated failures */
-        if (++curv_fail >= ORC_CURV_FAIL_MAX) gn_sticky = 1;
+        /* Gauss-Newton fallback for this iteration; latched after repeated failures (the unicycle: backed off instead) */
+        if (dd_curv(d)) { curv_back = curv_back ? (curv_back < 16 ? 2 * curv_back : 16) : 1; curv_skip = curv_back; }
+        else if (++curv_fail >= ORC_CURV_FAIL_MAX) gn_sticky = 1;
         tl_passes++;
         use_curv = 0;
         continue;
       }
-      if (accepted && use_curv) curv_fail = 0;
+      if (accepted && use_curv) { curv_fail = 0; curv_back = 0; }
       /* the arms: a Gauss-Newton step accepted at full length releases the latch (the failures that set it
        * belong to the first iterations of a warm start, where the fraction to the boundary cuts the steps) */
-      if (accepted && !use_curv && ls == 0 && with_fk_curv(d)) { gn_sticky = 0; curv_fail = 0; }
+      if (accepted && !use_curv && ls == 0 && arm_curv(d)) { gn_sticky = 0; curv_fail = 0; }
       if (accepted) ls_start = ls > ORC_LS_GROW ? ls - ORC_LS_GROW : 0;
       break;
     }

@@ -85,6 +85,7 @@ constexpr double kMuDiverged = 1e12;
 constexpr double kCurvMu = 1e-2; // curvature terms only once the barrier parameter is this small
 constexpr int kLsCurv = 2;        // trials granted to a step computed with constraint curvature
 constexpr int kCurvFailMax = 2;   // consecutive curvature-step failures before Gauss-Newton is latched
+constexpr int kCurvBackMax = 16;  // (diff-drive) longest run of iterations a failed curvature step switches the terms off
 constexpr int kGroupedMin = 512;    // list length from which the grouped Riccati blocks are used
 constexpr double kAccFeas = 1e-6; // acceptable termination: feasibility / complementarity level
 constexpr int kDenseDiv = 8;      // identity list while more than B / kDenseDiv instances iterate; below: compacted list,
@@ -122,6 +123,7 @@ struct Ws {
   double *res_stat, *res_eq, *res_ineq, *res_comp, *obj;
   int *status, *iters, *ls, *cur, *newstep;
   int *redo, *force_gn, *gn_sticky, *curv_fail, *usedc, *stall;
+  int *curv_skip, *curv_back;     // (diff-drive) curvature steps still to be skipped / length of the last skip (back-off)
   int *ls0, *lsst;                // halvings the current line search started from / the next one starts from
   int *active_hist;               // [max_passes] instances still iterating after each pass
   int *act_idx, *n_act;           // compacted list of the instances still iterating, its length
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(256) void k_init(Ws W, const double *__restrict__ x
   W.amin_p[b] = (unsigned long long)__double_as_longlong(1.0);
   W.amin_d[b] = (unsigned long long)__double_as_longlong(1.0);
   W.redo[b] = 0; W.force_gn[b] = 0; W.gn_sticky[b] = 0; W.curv_fail[b] = 0; W.usedc[b] = 0; W.stall[b] = 0;
+  W.curv_skip[b] = 0; W.curv_back[b] = 0;
   W.ls0[b] = 0; W.lsst[b] = 0;
   W.mu[b] = warm ? warm_mu(W.wmu[b], mu0) : mu0;
   W.rho[b] = 0.0;
@@ -412,6 +415,7 @@ __global__ __launch_bounds__(64) void k_migrate(const Ws S, const Ws D, int n, i
     D.status[li] = S.status[b]; D.iters[li] = S.iters[b]; D.ls[li] = S.ls[b]; D.newstep[li] = S.newstep[b];
     D.redo[li] = S.redo[b]; D.force_gn[li] = S.force_gn[b]; D.gn_sticky[li] = S.gn_sticky[b];
     D.curv_fail[li] = S.curv_fail[b]; D.usedc[li] = S.usedc[b]; D.stall[li] = S.stall[b];
+    D.curv_skip[li] = S.curv_skip[b]; D.curv_back[li] = S.curv_back[b];
     D.ls0[li] = S.ls0[b]; D.lsst[li] = S.lsst[b];
     D.cur[li] = 0;
     D.orig[li] = b;
@@ -663,11 +667,12 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
   // ---- accumulators --------------------------------------------------------
   double gf[NV], q0[NV], q1[NV], rs[NV], Dg[NV], cs[NV];
   double Qqq[NQ][NQ];
-  double Cqq[C::CURV ? NQ : 1][C::CURV ? NQ : 1];  // sum_i (lambda_i + cN/h^2) grad^2 h_i of the distance rows
+  constexpr bool QC = C::CURV || C::DDCURV;   // the record carries a curvature block of the q variables
+  double Cqq[QC ? NQ : 1][QC ? NQ : 1];  // sum_i (lambda_i + cN/h^2) grad^2 h_i of the distance rows
 #pragma unroll
-  for (int a = 0; a < (C::CURV ? NQ : 1); a++)
+  for (int a = 0; a < (QC ? NQ : 1); a++)
 #pragma unroll
-    for (int c = 0; c < (C::CURV ? NQ : 1); c++) Cqq[a][c] = 0;
+    for (int c = 0; c < (QC ? NQ : 1); c++) Cqq[a][c] = 0;
 #pragma unroll
   for (int j = 0; j < NV; j++) { gf[j] = 0; q0[j] = 0; q1[j] = 0; rs[j] = 0; Dg[j] = 0; cs[j] = 0; }
 #pragma unroll
@@ -884,6 +889,12 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
     if (SL >= v.nslots()) return;
     Vec3 J[NQ];
     const Vec3 Pt = kin.template point<SL>(v, J);
+    // (DDCURV) the frames ride on the base, p = (x, y) + R(theta) o: d2 p / dtheta2 = -(p - (x, y)); a pair: -(pa - pb)
+    Vec3 ddP = {0, 0, 0};
+    if constexpr (C::DDCURV) {
+      if (v.slot_fb(SL) >= 0) ddP = {-Pt.x, -Pt.y, 0.0};
+      else ddP = {-(kin.pa[SL].x - kin.qx), -(kin.pa[SL].y - kin.qy), 0.0};
+    }
     // (FKCURV) sum over the slot's rows of (multiplier + inverse-barrier weight) x unit direction of the row, minus
     // the goal cost's 2 w e: what the second derivatives of the slot's point are contracted with
     Vec3 Fc = {0, 0, 0};
@@ -915,6 +926,10 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         TQ[0] += 2.0 * w0; TQ[3] += 2.0 * w1; TQ[5] += 2.0 * w2;
         Fc = {-2.0 * w0 * e0, -2.0 * w1 * e1, -2.0 * w2 * e2};
       }
+      if constexpr (C::DDCURV) {
+        // what Gauss-Newton leaves out: 2 sum_c w_c e_c d2 p_c / dtheta2 (added to Q: subtracted from the block that is subtracted)
+        Cqq[2][2] -= 2.0 * (w0 * e0 * ddP.x + w1 * e1 * ddP.y);
+      }
     }
     auto fk_row_body = [&](const int r, const FkBuf &Bf) __attribute__((always_inline)) {
       const int i = v.fk_row(r), kind = v.fk_kind(r);
@@ -928,6 +943,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
       }
       double gq[NQ];
       double h, cinv = 0.0;
+      double ndd = 0.0;      // unit direction of the row . d2 p / dtheta2 (DDCURV)
       Vec3 nd = {0, 0, 0};   // unit direction of the row in the slot's point (FKCURV)
       if (kind == ROW_RADIAL) {
         // ||fk_l(q) - c_i|| - r_i - r_body (mpcBase.py:82-101)
@@ -936,6 +952,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         h = dist - Bf.op[3] - rbody;
         cinv = 1.0 / dist;
         if constexpr (C::FKCURV) nd = {dv.x * cinv, dv.y * cinv, dv.z * cinv};
+        if constexpr (C::DDCURV) ndd = dot(dv, ddP) * cinv;
 #pragma unroll
         for (int a = 0; a < NQ; a++) gq[a] = dot(dv, J[a]) * cinv;
       } else if (kind == ROW_LINEAR) {
@@ -946,6 +963,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         const double sgn = sd < 0 ? -1.0 : 1.0;
         h = fabs(sd) / nrm - rbody;
         if constexpr (C::FKCURV) nd = {sgn * av.x / nrm, sgn * av.y / nrm, sgn * av.z / nrm};
+        if constexpr (C::DDCURV) ndd = sgn * dot(av, ddP) / nrm;
 #pragma unroll
         for (int a = 0; a < NQ; a++) gq[a] = sgn * dot(av, J[a]) / nrm;
       } else {
@@ -954,6 +972,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         h = dist - 2.0 * rbody;
         cinv = 1.0 / dist;
         if constexpr (C::FKCURV) nd = {Pt.x * cinv, Pt.y * cinv, Pt.z * cinv};
+        if constexpr (C::DDCURV) ndd = dot(Pt, ddP) * cinv;
 #pragma unroll
         for (int a = 0; a < NQ; a++) gq[a] = dot(Pt, J[a]) * cinv;
       }
@@ -962,6 +981,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
       if (k == 0 && NS == 0) {
         h = 1.0;
         cinv = 0.0;
+        ndd = 0.0;
         nd = {0, 0, 0};
 #pragma unroll
         for (int a = 0; a < NQ; a++) gq[a] = 0.0;
@@ -1011,7 +1031,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
         rs[NX] -= rw.lv;
         Dg[NX] += rw.sig;
       }
-      if constexpr (C::CURV) {
+      if constexpr (QC) {
         // exact Hessian of the distance rows when the kinematics are affine in q:
         // grad^2 h = (J^T J - g g^T) / dist, weighted by the multiplier and the inverse-barrier term
         // (weight selected, not branched on: the rows of the slot stay one basic block)
@@ -1027,6 +1047,8 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
           for (int a = 0; a < NQ; a++)
 #pragma unroll
             for (int c = a; c < NQ; c++) Cqq[a][c] += wgt * (dot(J[a], J[c]) - gq[a] * gq[c]);
+          // (the unicycle: the frame turns with the base -- the row's direction times d2 p / dtheta2)
+          if constexpr (C::DDCURV) Cqq[2][2] += M.use_curv ? (rw.lv + cw) * ndd : 0.0;
         }
       }
     };
@@ -1132,6 +1154,32 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
       for (int i = 0; i < 25; i++) rec[C::R_A5 + i] = A5[i];
 #pragma unroll
       for (int i = 0; i < 10; i++) rec[C::R_B5 + i] = B5[i];
+      {
+        // nu . grad^2 Phi of the discrete dynamics (ERK2 midpoint, 5 nodes; closed form of diffdrive_step):
+        // x+ = x + h sum_n cos(al_n) be_n, y+ = y + h sum_n sin(al_n) be_n, al_n = theta + a_n omega + b_n u1,
+        // be_n = v + a_n u0, a_n = (n + 1/2) h, b_n = h^2 n (n + 1) / 2 -- only the costates of x and y carry curvature:
+        // D = h sum_n [(-nx cos - ny sin) be_n ga ga^T + (-nx sin + ny cos)(ga gb^T + gb ga^T)], ga = (1, a_n, b_n) over
+        // (theta, omega, u1), gb = (1, a_n) over (v, u0).  Stored negated (the recursion subtracts cwt x the entry).
+        const double hn = M.dt / kErkNodes;
+        const double th = z[2], vv = z[6], om = z[7], u0 = z[NX + NS], u1 = z[NX + NS + 1];
+        double Dd[C::ND + 1];
+#pragma unroll
+        for (int i = 0; i <= C::ND; i++) Dd[i] = 0.0;
+#pragma unroll 1
+        for (int nn_ = 0; nn_ < kErkNodes; nn_++) {
+          const double an = (nn_ + 0.5) * hn, bn = hn * hn * (double)(nn_ * (nn_ + 1)) * 0.5;
+          double sn, cn;
+          sincos(th + an * om + bn * u1, &sn, &cn);
+          const double be = vv + an * u0;
+          const double Pn = hn * (-nun[0] * cn - nun[1] * sn) * be, Sn = hn * (-nun[0] * sn + nun[1] * cn);
+          Dd[0] += Pn * an; Dd[1] += Pn * bn; Dd[2] += Pn * an * an; Dd[3] += Pn * an * bn; Dd[4] += Pn * bn * bn;
+          Dd[5] += Sn; Dd[6] += Sn * an; Dd[7] += Sn * an; Dd[8] += Sn * an * an; Dd[9] += Sn * bn; Dd[10] += Sn * bn * an;
+          Dd[C::ND] += Pn;   // (theta, theta): into the q block
+        }
+#pragma unroll
+        for (int i = 0; i < C::ND; i++) rec[C::R_D + i] = M.use_curv ? -Dd[i] : 0.0;
+        Cqq[2][2] -= M.use_curv ? Dd[C::ND] : 0.0;
+      }
       // A = I outside the reduced block
 #pragma unroll
       for (int j = 3; j < 6; j++) rs[j] += nun[j];
@@ -1159,7 +1207,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
     } else {
       // (see the holonomic chain: every entry the recursion reads is written)
 #pragma unroll
-      for (int i = 0; i < 35; i++) rec[C::R_A5 + i] = 0.0;
+      for (int i = 0; i < 35 + C::ND; i++) rec[C::R_A5 + i] = 0.0;
 #pragma unroll
       for (int j = 0; j < NX; j++) rec[C::R_RC + j] = 0.0;
     }
@@ -1206,7 +1254,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
 #pragma unroll
       for (int c = a; c < NQ; c++) {
         if constexpr (QLDS) rec[C::R_C + s] = M.use_curv ? (double)qacc[(C::NQ2 + s) * kSweepBlock] : 0.0;
-        else rec[C::R_C + s] = (C::CURV && M.use_curv) ? Cqq[C::CURV ? a : 0][C::CURV ? c : 0] : 0.0;
+        else rec[C::R_C + s] = (QC && M.use_curv) ? Cqq[QC ? a : 0][QC ? c : 0] : 0.0;
         s++;
       }
   }
@@ -1378,14 +1426,14 @@ __device__ __forceinline__ void wave_reduce_many(double (&sums)[NS_], double (&m
 struct Inst {
   double mu, rho, phi0, Dd, fcur, thcur, logcur, res_stat, res_eq, res_ineq, res_comp, obj;
   double amin_p, amin_d;   // fraction-to-the-boundary step lengths of the current step
-  int status, iters, ls, ls0, lsst, cur, newstep, redo, force_gn, gn_sticky, curv_fail, usedc, stall;
+  int status, iters, ls, ls0, lsst, cur, newstep, redo, force_gn, gn_sticky, curv_fail, usedc, stall, curv_skip, curv_back;
 };
 __device__ __forceinline__ void inst_init(Inst &s, double mu0) {
   s.mu = mu0; s.rho = 0.0; s.phi0 = 0.0; s.Dd = 0.0; s.fcur = 0.0; s.thcur = 0.0; s.logcur = 0.0;
   s.res_stat = 0.0; s.res_eq = 0.0; s.res_ineq = 0.0; s.res_comp = 0.0; s.obj = 0.0;
   s.amin_p = 1.0; s.amin_d = 1.0;
   s.status = ST_ACTIVE; s.iters = 0; s.ls = 0; s.ls0 = 0; s.lsst = 0; s.cur = 0; s.newstep = 0; s.redo = 0;
-  s.force_gn = 0; s.gn_sticky = 0; s.curv_fail = 0; s.usedc = 0; s.stall = 0;
+  s.force_gn = 0; s.gn_sticky = 0; s.curv_fail = 0; s.usedc = 0; s.stall = 0; s.curv_skip = 0; s.curv_back = 0;
 }
 __device__ __forceinline__ void inst_load(Inst &s, const Ws &W, int b) {
   s.mu = W.mu[b]; s.rho = W.rho[b]; s.phi0 = W.phi0[b]; s.Dd = W.Dd[b]; s.fcur = W.fcur[b]; s.thcur = W.thcur[b];
@@ -1394,7 +1442,7 @@ __device__ __forceinline__ void inst_load(Inst &s, const Ws &W, int b) {
   s.amin_p = __longlong_as_double((long long)W.amin_p[b]); s.amin_d = __longlong_as_double((long long)W.amin_d[b]);
   s.status = W.status[b]; s.iters = W.iters[b]; s.ls = W.ls[b]; s.ls0 = W.ls0[b]; s.lsst = W.lsst[b]; s.cur = W.cur[b];
   s.newstep = W.newstep[b]; s.redo = W.redo[b]; s.force_gn = W.force_gn[b]; s.gn_sticky = W.gn_sticky[b];
-  s.curv_fail = W.curv_fail[b]; s.usedc = W.usedc[b]; s.stall = W.stall[b];
+  s.curv_fail = W.curv_fail[b]; s.usedc = W.usedc[b]; s.stall = W.stall[b]; s.curv_skip = W.curv_skip[b]; s.curv_back = W.curv_back[b];
 }
 __device__ __forceinline__ void inst_store(const Inst &s, const Ws &W, int b) {
   W.mu[b] = s.mu; W.rho[b] = s.rho; W.phi0[b] = s.phi0; W.Dd[b] = s.Dd; W.fcur[b] = s.fcur; W.thcur[b] = s.thcur;
@@ -1403,7 +1451,7 @@ __device__ __forceinline__ void inst_store(const Inst &s, const Ws &W, int b) {
   W.amin_p[b] = (unsigned long long)__double_as_longlong(s.amin_p); W.amin_d[b] = (unsigned long long)__double_as_longlong(s.amin_d);
   W.status[b] = s.status; W.iters[b] = s.iters; W.ls[b] = s.ls; W.ls0[b] = s.ls0; W.lsst[b] = s.lsst; W.cur[b] = s.cur;
   W.newstep[b] = s.newstep; W.redo[b] = s.redo; W.force_gn[b] = s.force_gn; W.gn_sticky[b] = s.gn_sticky;
-  W.curv_fail[b] = s.curv_fail; W.usedc[b] = s.usedc; W.stall[b] = s.stall;
+  W.curv_fail[b] = s.curv_fail; W.usedc[b] = s.usedc; W.stall[b] = s.stall; W.curv_skip[b] = s.curv_skip; W.curv_back[b] = s.curv_back;
 }
 
 // whole-horizon sums / maxima of the trial point the last sweep evaluated (+ the merit slope of the step)
@@ -1451,9 +1499,16 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
         if (usedc) {
           // the curvature step failed its line search: recompute this iteration's step with
           // the Gauss-Newton blocks (null pass next); latch after repeated failures
-          const int cf = s.curv_fail + 1;
-          s.curv_fail = cf;
-          if (cf >= kCurvFailMax) s.gn_sticky = 1;
+          if constexpr (C::DDCURV) {
+            // (the unicycle: the next curvature steps are skipped -- 1, 2, 4 .. 16 iterations, doubling with every
+            //  failure in a row, over after a success -- instead of a latch: DESIGN.md 3)
+            s.curv_back = s.curv_back ? (s.curv_back < kCurvBackMax ? 2 * s.curv_back : kCurvBackMax) : 1;
+            s.curv_skip = s.curv_back;
+          } else {
+            const int cf = s.curv_fail + 1;
+            s.curv_fail = cf;
+            if (cf >= kCurvFailMax) s.gn_sticky = 1;
+          }
           s.redo = 1;
           s.force_gn = 1;
           s.ls = 0;
@@ -1465,7 +1520,7 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
       s.ls = ls;
       return false;  // next sweep retries with alpha / 2
     }
-    if (usedc) s.curv_fail = 0;
+    if (usedc) { s.curv_fail = 0; s.curv_back = 0; }
     // the arms: a Gauss-Newton step accepted at full length releases the latch (the failures that set it belong to
     // the first iterations of a warm start, where the fraction to the boundary cuts the steps)
     if constexpr (C::FKCURV) {
@@ -1526,7 +1581,11 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
     return false;
   }
   // exact constraint curvature unless latched off or this is the fallback pass
-  if constexpr (C::CURV) usec = M.use_curv && !s.gn_sticky && !s.force_gn && (mu <= kCurvMu);
+  if constexpr (C::CURV || C::DDCURV) usec = M.use_curv && !s.gn_sticky && !s.force_gn && (mu <= kCurvMu);
+  if constexpr (C::DDCURV) {
+    // (a fallback pass -- force_gn -- is not an iteration of its own: the skip counter moves once per iteration)
+    if (usec && s.curv_skip > 0) { s.curv_skip--; usec = false; }
+  }
   s.force_gn = 0;
   // a step with the exact curvature is tried at full length first
   const int lsb = usec ? 0 : lsst;
@@ -1535,9 +1594,13 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
   return true;
 }
 // after the recursion: a failed factorisation either falls back to Gauss-Newton (null pass) or stops the instance
-__device__ __forceinline__ void inst_after_recursion(Inst &s, const bool chol_ok, const bool usec) {
+__device__ __forceinline__ void inst_after_recursion(Inst &s, const bool chol_ok, const bool usec, const bool backoff = false) {
   if (!chol_ok) {
     if (usec) {
+      if (backoff) {   // (diff-drive: see inst_decide)
+        s.curv_back = s.curv_back ? (s.curv_back < kCurvBackMax ? 2 * s.curv_back : kCurvBackMax) : 1;
+        s.curv_skip = s.curv_back;
+      }
       // reduced Hessian not positive definite with the curvature terms: recompute this
       // iteration's step with the Gauss-Newton blocks (null pass next); not counted as a
       // line-search failure
@@ -1684,13 +1747,28 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
       if (hi < NQ) {
         const int s = lo * NQ - lo * (lo - 1) / 2 + (hi - lo);
         qp[u] = C::R_Q + s;
-        if constexpr (C::CURV) cp[u] = C::R_C + s;
+        if constexpr (C::CURV || C::DDCURV) cp[u] = C::R_C + s;
       } else if (lo == hi) {
         qp[u] = C::R_DG + (lo - NQ);
       } else if (NS > 0 && lo == NX) {
         qp[u] = C::R_CS + hi;
       } else if (NS > 0 && hi == NX) {
         qp[u] = C::R_CS + lo;
+      }
+      if constexpr (C::DDCURV) {
+        // curvature of the unicycle's dynamics outside the q block: variables theta (2), omega (7), u1 | v (6), u0
+        auto cls = [](int j) __attribute__((always_inline)) {   // 0 theta, 1 omega, 2 u1, 3 v, 4 u0, -1 none
+          return j == 2 ? 0 : (j == 7 ? 1 : (j == NX + NS + 1 ? 2 : (j == 6 ? 3 : (j == NX + NS ? 4 : -1))));
+        };
+        const int ci = cls(i), cj = cls(j);
+        if (ci >= 0 && cj >= 0 && !(ci == 0 && cj == 0)) {
+          const int a = ci < cj ? ci : cj, b = ci < cj ? cj : ci;
+          // (a, b): alpha-alpha pairs (0,1) (0,2) (1,1) (1,2) (2,2) -> 0 .. 4; alpha-beta pairs (a, 3 + t) -> 5 + 2 a + t
+          int idx = -1;
+          if (b <= 2) idx = a == 0 ? b - 1 : (a == 1 ? 1 + b : 4);
+          else if (a <= 2) idx = 5 + 2 * a + (b - 3);
+          if (idx >= 0) cp[u] = C::R_D + idx;
+        }
       }
     }
   }
@@ -1979,11 +2057,11 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     rowsrc(lq, qco, qcs, qI);
     const int lr = lane < NX ? lane : 0;
     // record entries of the stage about to be processed, one stage ahead
-    double rq[EPL], q0n = 0, q1n = 0, rcn = 0, abn[2] = {0, 0};
+    double rq[EPL], rqk[EPL], q0n = 0, q1n = 0, rcn = 0, abn[2] = {0, 0};
     auto fetch_dd = [&](int k) __attribute__((always_inline)) {
       const RP *const r = rb + (size_t)k * sstr;
 #pragma unroll
-      for (int u = 0; u < EPL; u++) rq[u] = r[qp[u]];
+      for (int u = 0; u < EPL; u++) { rq[u] = r[qp[u]]; rqk[u] = r[cp[u]]; }
       q0n = r[C::R_Q0 + lq]; q1n = r[C::R_Q1 + lq]; rcn = r[C::R_RC + lr];
 #pragma unroll
       for (int u = 0; u < 2; u++) abn[u] = r[C::R_A5 + (lane + LPI * u < 35 ? lane + LPI * u : 0)];
@@ -2037,9 +2115,10 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
     for (int k = N - 1; k >= 0; k--) {
       gdouble *const kpk = kpb + (size_t)k * kps;
       // this stage's record entries are in registers; the next one's leave now
+      // (with the second-order terms of the unicycle: record entry minus the curvature entry when this step uses them)
       double rqc[EPL];
 #pragma unroll
-      for (int u = 0; u < EPL; u++) rqc[u] = rq[u];
+      for (int u = 0; u < EPL; u++) rqc[u] = rq[u] - cwt * rqk[u];
       const double q0c = q0n, q1c = q1n, rcc = rcn;
       // ([A5 | B5] and rc of THIS stage are in LDS since the last phase of the previous stage)
       if (k > 0) fetch_dd(k - 1);
@@ -2089,7 +2168,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < EPL; u++) {
-            double v = rqc[u];   // (the diff-drive model carries no curvature block: cwt * 0)
+            double v = rqc[u];
 #pragma unroll
             for (int r = 0; r < NR; r++) v += ba[u][r] * bb[u][r];
             v += bI[u] ? bi[u] : 0.0;
@@ -3089,7 +3168,13 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   if (L0) {
     // = inst_after_recursion on the stored words
     if (!chol_ok) {
-      if (usec) { W.redo[b] = 1; W.force_gn[b] = 1; W.usedc[b] = 0; }
+      if (usec) {
+        W.redo[b] = 1; W.force_gn[b] = 1; W.usedc[b] = 0;
+        if constexpr (C::DDCURV) {
+          const int cb = s.curv_back ? (s.curv_back < kCurvBackMax ? 2 * s.curv_back : kCurvBackMax) : 1;
+          W.curv_back[b] = cb; W.curv_skip[b] = cb;
+        }
+      }
       else W.status[b] = -5;
     } else {
       W.usedc[b] = usec ? 1 : 0;
@@ -4084,7 +4169,7 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1), di
       rec_ok = ok;
     }
     unpark();
-    if (recurse) inst_after_recursion(s, rec_ok, usec);
+    if (recurse) inst_after_recursion(s, rec_ok, usec, C::DDCURV);
     GSYNC();   // dz, nunew
     STAMP_B(st_ric);
     // ---- step lengths of the new step -----------------------------------------------------------------
@@ -5054,6 +5139,7 @@ static int build_model(const rmpc_desc &d, DevModel &M, std::string &err) {
     if (d.module_kind[mi] == RMPC_MOD_SELFCOLLISION)
       for (int p = 0; p < d.n_pairs; p++) curv = curv && affine(d.pair_frame[p][0]) && affine(d.pair_frame[p][1]);
   }
+  if (d.robot == RMPC_ROBOT_DIFFDRIVE) curv = true;   // exact second-order terms of the unicycle (Cfg::DDCURV)
   M.use_curv = curv ? 1 : 0;
   if (getenv("RMPC_NO_CURV")) M.use_curv = 0;  // debugging aid
   return 0;
@@ -5194,7 +5280,7 @@ static RecLayout rec_layout(const DevModel &M) {
   L.q = 0; L.c = nq2; L.dg = 2 * nq2; L.cs = L.dg + (M.nv - M.n);
   L.q0 = L.cs + (M.ns > 0 ? M.nv : 0); L.q1 = L.q0 + M.nv; L.rc = L.q1 + M.nv;
   L.a5 = L.rc + M.nx; L.b5 = L.a5 + 25;
-  L.rw = L.a5 + (M.robot == RMPC_ROBOT_DIFFDRIVE ? 35 : 0);
+  L.rw = L.a5 + (M.robot == RMPC_ROBOT_DIFFDRIVE ? 35 + 11 : 0);   // (+ Cfg::ND curvature entries)
   L.rs = (L.rw + 1 + 7) / 8 * 8;
   return L;
 }
@@ -5230,7 +5316,7 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
                     &W.res_stat, &W.res_eq, &W.res_ineq, &W.res_comp, &W.obj};
   for (auto pp : per) *pp = c.take<double>(Bp);
   int **peri[] = {&W.status, &W.iters, &W.ls, &W.cur, &W.newstep, &W.redo, &W.force_gn, &W.gn_sticky, &W.curv_fail, &W.usedc, &W.stall,
-                  &W.ls0, &W.lsst};
+                  &W.ls0, &W.lsst, &W.curv_skip, &W.curv_back};
   for (auto pp : peri) *pp = c.take<int>(Bp);
   W.active_hist = c.take<int>(max_passes + 8);
   W.act_idx = c.take<int>(Bp);

@@ -214,6 +214,13 @@ struct Cfg {
   // tolerance at a linear rate of 0.6 per iteration.
   static constexpr bool CURV = (ROBOT_ == RMPC_ROBOT_CHAIN) && (NS_ == 0);
   static constexpr bool FKCURV = CURV && (NQ_ > 3);
+  // The diff-drive base (round 4): exact second-order terms of the unicycle -- nu . grad^2 Phi of the discrete dynamics
+  // (only x+ and y+ are curved: block over theta, omega, u1 | v, u0, record entries R_D) and the rotation of off-centre
+  // frames (d2 p / dtheta2, in the q block R_C together with the distance rows' own curvature).  Without them the
+  // Gauss-Newton blocks of the unicycle converge linearly: cold boxers 20.6 -> 15.9 iterations, every instance to the
+  // 1e-6 tolerance instead of 9 in 10 (oracle, 256 instances of BASELINE configs[2]).
+  static constexpr bool DDCURV = (ROBOT_ == RMPC_ROBOT_DIFFDRIVE);
+  static constexpr int ND = 11;   // (th,om) (th,u1) (om,om) (om,u1) (u1,u1) | (th,v) (th,u0) (om,v) (om,u0) (u1,v) (u1,u0)
   // instances (wavefronts) per block of the grouped Riccati kernel.  Small blocks: with the instance-major
   // records neighbouring instances no longer share cache lines, a 4-wavefront block fits beside a k_sweep
   // wavefront of another batch on every SIMD (a 16-wavefront block needs four free slots per SIMD at once);
@@ -243,7 +250,8 @@ struct Cfg {
   static constexpr int R_RC = R_Q1 + NV;
   static constexpr int R_A5 = R_RC + NX;
   static constexpr int R_B5 = R_A5 + 25;
-  static constexpr int RW = R_A5 + (ROBOT_ == RMPC_ROBOT_DIFFDRIVE ? 35 : 0);
+  static constexpr int R_D = R_B5 + 10;           // (diff-drive) MINUS the dynamics' curvature entries: Q = r0 - cwt r1 adds them
+  static constexpr int RW = R_A5 + (ROBOT_ == RMPC_ROBOT_DIFFDRIVE ? 35 + ND : 0);
   static constexpr int R_ZERO = RW;             // always 0.0: source of the structural zeros of the dense blocks
   static constexpr int RS = (RW + 1 + 7) / 8 * 8;   // record stride (doubles)
   // fused kernel: the stage records of the owner wavefront's two instances stay in LDS when they are small

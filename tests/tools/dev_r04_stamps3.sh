@@ -1,0 +1,5 @@
+set -e
+mkdir -p gpurun_out
+export RMPC_ALLOW_STALE=1
+RMPC_LIB_PATH=$PWD/robot_mpcs_amd/csrc/librmpc_hip_dev.so timeout -k 10 300 python scripts/fused_stamps.py cfg3 4096 > gpurun_out/r04_cfg3_stamps.txt 2>&1 || { tail gpurun_out/r04_cfg3_stamps.txt; exit 1; }
+grep -v amdgpu gpurun_out/r04_cfg3_stamps.txt
