@@ -41,6 +41,7 @@ FP64_VECTOR_TFLOPS = 78.6
 # `roofline` are the nominal accounting of SURVEY.md 8(d), not the limiter
 BOUND_BY_COUNTERS = {
     "k_fused": "latency (one wavefront per SIMD: fp64 dependency chains + LDS round trips of the recursion; iterate streamed through L2 / Infinity Cache)",
+    "k_fused_arm": "vector-instruction issue of one wavefront per SIMD (sweep: 15 k instructions per lane and pass, 40 of 64 lanes busy), then the recursion's dependency chains (7 x 7 factorisation) and LDS round trips",
     "k_sweep": "latency (memory requests at one wavefront per SIMD), then fp64 vector issue",
     "k_riccati": "latency (LDS round trips, 7x7 factorisation chain)",
     "k_step": "memory latency",
@@ -193,10 +194,10 @@ def kernel_report(prof, wall_ms, nsteps, B, d, iters_mean):
     v = kern[name]
     avg_ms = v["total_ms"] / v["launches"]
     io, ws, per_solve, fl = survey_bytes_per_solve(d, iters_mean)
-    if name == "k_fused":
+    if name in ("k_fused", "k_fused_arm"):
         # one launch = B whole solves: SURVEY 8(d)'s per-solve figure x B
         alg = B * per_solve
-        note = "k_fused carries B whole solves per launch: algorithmic bytes = B x (IO + iters_mean x WS) of SURVEY.md 8(d)"
+        note = name + " carries B whole solves per launch: algorithmic bytes = B x (IO + iters_mean x WS) of SURVEY.md 8(d)"
     else:
         alg = v["total_alg_bytes"] / v["launches"]   # pass kernels: bytes of the lanes still active, averaged (fill_lane_bytes)
         note = "pass kernel: algorithmic bytes of the lanes still iterating in each launch, averaged over the launches"
@@ -228,7 +229,7 @@ def kernel_report(prof, wall_ms, nsteps, B, d, iters_mean):
                           "note": "one handle on one stream, HIP events around every kernel; kernel time <= wall time"},
         "per_solve": {"compulsory_io_bytes": io, "workspace_bytes_per_iteration": ws, "iters_mean": iters_mean,
                       "flops_per_iteration": fl},
-        "compulsory_io_GBps": B * io / (avg_ms * 1e-3) / 1e9 if name == "k_fused" else None,
+        "compulsory_io_GBps": B * io / (avg_ms * 1e-3) / 1e9 if name in ("k_fused", "k_fused_arm") else None,
         "note": note,
         "all_kernels": {k: {"total_ms": round(p["total_ms"], 3), "launches": int(p["launches"]),
                             "avg_ms": p["total_ms"] / p["launches"],

@@ -164,6 +164,9 @@ int rmpc_set_pass_budget(rmpc_handle *h, int passes);
  * diff-drive base, N <= 32) -- rmpc_solve_batch_device then only enqueues work on the stream and returns; 0 when they
  * run as pass kernels, whose host loop reads a counter every few passes and returns when the batch is done. */
 int rmpc_is_fused(const rmpc_handle *h);
+/* the kernel behind a fused handle: "k_fused" (point robot, diff-drive base: two instances per wavefront, lane = stage),
+ * "k_fused_arm" (arms with 5 .. 7 joints: one instance per wavefront, a stage per two lanes), "" for the pass kernels */
+const char *rmpc_fused_kernel_name(const rmpc_handle *h);
 
 /* 1 when rmpc_solve_batch_device (and the scene / packed variants) of this handle only ENQUEUES work on the stream and
  * returns -- no look from the host, the solve is ordered with the caller's stream like any kernel: fused handles
@@ -178,7 +181,8 @@ int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch);
 
 /* Per-kernel timing with HIP events on the solver's stream.
  * kernels: 0 pack, 1 sweep, 2 riccati, 3 step, 4 unpack (pass kernels: large horizons, the arm),
- * 5 fused (whole solves inside one wavefront: point robot and diff-drive base, N <= 32). */
+ * 5 fused (whole solves inside one wavefront, N <= 32: point robot, diff-drive base, arms with 5 .. 7 joints --
+ *   rmpc_fused_kernel_name tells which kernel). */
 #define RMPC_NUM_KERNELS 6
 int rmpc_set_profiling(rmpc_handle *h, int enable);
 /* total_ms / launches: summed HIP-event durations and launch counts per kernel;

@@ -294,6 +294,14 @@ static int dd_curv(const orc_desc *d) {
   if (on < 0) { const char *e = getenv("ORC_DD_CURV"); on = (e && e[0] == '0') ? 0 : 1; }
   return d->robot == ORC_ROBOT_DIFFDRIVE && on;
 }
+/* Models whose failed curvature steps are BACKED OFF (the terms are switched off for 1, 2, 4 .. 16 iterations, see
+ * solve_impl) instead of latched off: the unicycle, and (round 4) the small holonomic chains -- on the BASELINE point
+ * robots the slowest instance of a batch of 4096 needs 66 - 68 passes instead of 82 - 95 at an unchanged mean (13.97 vs
+ * 13.99; three seeds; warm closed loops: 7.34 vs 7.40 passes per control step).  The arms keep the latch with its
+ * release rule (round 2): their cold solves see no failure at all. */
+static int backoff_model(const orc_desc *d) {
+  return dd_curv(d) || (d->robot == ORC_ROBOT_CHAIN && d->ns == 0 && d->n <= 3);
+}
 /* models whose distance rows and goal cost carry second derivatives of the kinematics */
 static int with_fk_curv(const orc_desc *d) { return arm_curv(d) || dd_curv(d); }
 
@@ -1065,7 +1073,7 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
     /* ---- step computation: exact constraint curvature first (when the model
      * qualifies and no fallback is latched), Gauss-Newton blocks otherwise ---- */
     int use_curv = curv_ok && !gn_sticky && mu <= ORC_CURV_MU;
-    if (use_curv && dd_curv(d) && curv_skip > 0) { curv_skip--; use_curv = 0; }
+    if (use_curv && backoff_model(d) && curv_skip > 0) { curv_skip--; use_curv = 0; }
     double alpha = 0.0, ad = 1.0;
     int ls = 0, accepted = 0, fatal = 0;
     for (;;) {
@@ -1103,7 +1111,7 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
         if (use_curv) {
           use_curv = 0;
           tl_passes++;
-          if (dd_curv(d)) { curv_back = curv_back ? (curv_back < 16 ? 2 * curv_back : 16) : 1; curv_skip = curv_back; }
+          if (backoff_model(d)) { curv_back = curv_back ? (curv_back < 16 ? 2 * curv_back : 16) : 1; curv_skip = curv_back; }
           continue; /* this iteration only */
         }
         fatal = 1;
@@ -1153,7 +1161,7 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
       }
       if (!accepted && use_curv) {
         /* Gauss-Newton fallback for this iteration; latched after repeated failures (the unicycle: backed off instead) */
-        if (dd_curv(d)) { curv_back = curv_back ? (curv_back < 16 ? 2 * curv_back : 16) : 1; curv_skip = curv_back; }
+        if (backoff_model(d)) { curv_back = curv_back ? (curv_back < 16 ? 2 * curv_back : 16) : 1; curv_skip = curv_back; }
         else if (++curv_fail >= ORC_CURV_FAIL_MAX) gn_sticky = 1;
         tl_passes++;
         use_curv = 0;

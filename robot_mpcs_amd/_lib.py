@@ -82,7 +82,7 @@ class RetargetArgs(C.Structure):
 # every symbol include/rmpc.h declares
 EXPORTED_SYMBOLS = [
     "rmpc_version", "rmpc_source_hash", "rmpc_last_error", "rmpc_desc_size", "rmpc_create", "rmpc_destroy", "rmpc_solve_batch",
-    "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_warm_start", "rmpc_set_pass_budget", "rmpc_is_fused", "rmpc_is_async", "rmpc_set_profiling", "rmpc_get_profile",
+    "rmpc_solve_batch_device", "rmpc_workspace_bytes", "rmpc_set_warm_start", "rmpc_set_pass_budget", "rmpc_is_fused", "rmpc_fused_kernel_name", "rmpc_is_async", "rmpc_set_profiling", "rmpc_get_profile",
     "rmpc_kernel_name", "rmpc_last_passes", "rmpc_debug_sweep", "rmpc_spec_source", "rmpc_spec_name", "rmpc_spec_for", "rmpc_debug_poison_lds",
     "rmpc_debug_fused_stamps", "rmpc_pack_scene_device", "rmpc_solve_batch_scene_device", "rmpc_pack_scene_workspace", "rmpc_solve_batch_packed_device", "rmpc_advance_device", "rmpc_advance_device_flags", "rmpc_retarget_device", "rmpc_advance_obstacles_device", "rmpc_free_space_device",
 ]
@@ -173,6 +173,8 @@ def load_library(path: str = LIB_PATH):
     L.rmpc_set_pass_budget.argtypes = [C.c_void_p, C.c_int]
     L.rmpc_is_fused.restype = C.c_int
     L.rmpc_is_fused.argtypes = [C.c_void_p]
+    L.rmpc_fused_kernel_name.restype = C.c_char_p
+    L.rmpc_fused_kernel_name.argtypes = [C.c_void_p]
     L.rmpc_is_async.restype = C.c_int
     L.rmpc_is_async.argtypes = [C.c_void_p]
     L.rmpc_last_passes.restype = C.c_int
@@ -471,8 +473,11 @@ class Solver:
         ms = (C.c_double * NUM_KERNELS)(); n = (C.c_int64 * NUM_KERNELS)()
         by = (C.c_double * NUM_KERNELS)(); full = (C.c_int64 * NUM_KERNELS)()
         self._check(self._L.rmpc_get_profile(self._h, ms, n, by, full), "rmpc_get_profile")
-        return {self._L.rmpc_kernel_name(i).decode(): dict(total_ms=ms[i], launches=n[i], total_alg_bytes=by[i],
-                                                           full_launch_bytes=full[i])
+        names = [self._L.rmpc_kernel_name(i).decode() for i in range(NUM_KERNELS)]
+        fused = self._L.rmpc_fused_kernel_name(self._h).decode()
+        if fused:
+            names[NUM_KERNELS - 1] = fused   # ("k_fused" or "k_fused_arm": the kernel this handle's launches run)
+        return {names[i]: dict(total_ms=ms[i], launches=n[i], total_alg_bytes=by[i], full_launch_bytes=full[i])
                 for i in range(NUM_KERNELS)}
 
     def fused_stamps(self, nblocks: int):

@@ -1499,9 +1499,9 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
         if (usedc) {
           // the curvature step failed its line search: recompute this iteration's step with
           // the Gauss-Newton blocks (null pass next); latch after repeated failures
-          if constexpr (C::DDCURV) {
-            // (the unicycle: the next curvature steps are skipped -- 1, 2, 4 .. 16 iterations, doubling with every
-            //  failure in a row, over after a success -- instead of a latch: DESIGN.md 3)
+          if constexpr (C::BACKOFF) {
+            // (the unicycle, the small chains: the next curvature steps are skipped -- 1, 2, 4 .. 16 iterations, doubling
+            //  with every failure in a row, over after a success -- instead of a latch: DESIGN.md 3)
             s.curv_back = s.curv_back ? (s.curv_back < kCurvBackMax ? 2 * s.curv_back : kCurvBackMax) : 1;
             s.curv_skip = s.curv_back;
           } else {
@@ -1582,7 +1582,7 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
   }
   // exact constraint curvature unless latched off or this is the fallback pass
   if constexpr (C::CURV || C::DDCURV) usec = M.use_curv && !s.gn_sticky && !s.force_gn && (mu <= kCurvMu);
-  if constexpr (C::DDCURV) {
+  if constexpr (C::BACKOFF) {
     // (a fallback pass -- force_gn -- is not an iteration of its own: the skip counter moves once per iteration)
     if (usec && s.curv_skip > 0) { s.curv_skip--; usec = false; }
   }
@@ -3170,7 +3170,7 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     if (!chol_ok) {
       if (usec) {
         W.redo[b] = 1; W.force_gn[b] = 1; W.usedc[b] = 0;
-        if constexpr (C::DDCURV) {
+        if constexpr (C::BACKOFF) {
           const int cb = s.curv_back ? (s.curv_back < kCurvBackMax ? 2 * s.curv_back : kCurvBackMax) : 1;
           W.curv_back[b] = cb; W.curv_skip[b] = cb;
         }
@@ -3427,7 +3427,13 @@ __global__ __launch_bounds__(64) void k_riccati_lane(const DevModel M, const Ws 
   }
   // = inst_after_recursion on the stored words
   if (!chol_ok) {
-    if (usec) { W.redo[b] = 1; W.force_gn[b] = 1; W.usedc[b] = 0; }
+    if (usec) {
+      W.redo[b] = 1; W.force_gn[b] = 1; W.usedc[b] = 0;
+      if constexpr (C::BACKOFF) {
+        const int cb = s.curv_back ? (s.curv_back < kCurvBackMax ? 2 * s.curv_back : kCurvBackMax) : 1;
+        W.curv_back[b] = cb; W.curv_skip[b] = cb;
+      }
+    }
     else W.status[b] = -5;
   } else {
     W.usedc[b] = usec ? 1 : 0;
@@ -4169,7 +4175,7 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1), di
       rec_ok = ok;
     }
     unpark();
-    if (recurse) inst_after_recursion(s, rec_ok, usec, C::DDCURV);
+    if (recurse) inst_after_recursion(s, rec_ok, usec, C::BACKOFF);
     GSYNC();   // dz, nunew
     STAMP_B(st_ric);
     // ---- step lengths of the new step -----------------------------------------------------------------
@@ -5966,6 +5972,10 @@ int rmpc_set_pass_budget(rmpc_handle *h, int passes) {
 }
 
 int rmpc_is_fused(const rmpc_handle *h) { return (h && h->fused) ? 1 : 0; }
+const char *rmpc_fused_kernel_name(const rmpc_handle *h) {
+  if (!h || !h->fused) return "";
+  return arm_fused_model(h->M) ? "k_fused_arm" : "k_fused";
+}
 int rmpc_is_async(const rmpc_handle *h) { return (h && (h->fused || h->pass_budget > 0)) ? 1 : 0; }
 
 int rmpc_set_profiling(rmpc_handle *h, int enable) {

@@ -220,6 +220,9 @@ struct Cfg {
   // Gauss-Newton blocks of the unicycle converge linearly: cold boxers 20.6 -> 15.9 iterations, every instance to the
   // 1e-6 tolerance instead of 9 in 10 (oracle, 256 instances of BASELINE configs[2]).
   static constexpr bool DDCURV = (ROBOT_ == RMPC_ROBOT_DIFFDRIVE);
+  // a failed curvature step switches the terms off for 1, 2, 4 .. 16 iterations (back-off) instead of latching them
+  // off: the unicycle and the small chains; the arms keep the latch with its release rule (oracle: backoff_model)
+  static constexpr bool BACKOFF = DDCURV || (CURV && !FKCURV);
   static constexpr int ND = 11;   // (th,om) (th,u1) (om,om) (om,u1) (u1,u1) | (th,v) (th,u0) (om,v) (om,u0) (u1,v) (u1,u0)
   // instances (wavefronts) per block of the grouped Riccati kernel.  Small blocks: with the instance-major
   // records neighbouring instances no longer share cache lines, a 4-wavefront block fits beside a k_sweep

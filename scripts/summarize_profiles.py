@@ -79,7 +79,14 @@ print(open(os.path.join(pdir, f"{tag}_{cfg}_pmc.csv")).read())
 tfile = os.path.join(pdir, "pmc_traffic.json")
 allt = json.load(open(tfile)) if os.path.exists(tfile) else {}
 allt[cfg] = traffic
-allt.setdefault("_meta", {})[cfg] = {"tag": tag, "fetch_correction": FETCH_CORR,
+# (the library the passes ran: the bench line printed under the profiler carries its source hash -- bench.py reports
+#  `traffic` only for that library)
+lib_hash = None
+try:
+    lib_hash = json.loads([l for l in open(os.path.join(go, f"prof_{tag}_{cfg}_s1.json")) if l.startswith("{")][-1]).get("library_source_hash")
+except Exception:   # noqa
+    pass
+allt.setdefault("_meta", {})[cfg] = {"tag": tag, "fetch_correction": FETCH_CORR, "library_source_hash": lib_hash,
                                      "source": f"profiles/{tag}_{cfg}_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                                "bench.py --streams 1; FETCH_SIZE x 1.976 + WRITE_SIZE, KiB -> bytes, mean over the launches)"}
 json.dump(allt, open(tfile, "w"), indent=1, sort_keys=True)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # development aid: the bench line in the driver's protocol (--steps 20 --warmup 5) and with the defaults, plus a digest
-TAG=${1:-r03}
+TAG=${1:-r04}
 timeout -k 10 500 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_${TAG}_driver.json 2> gpurun_out/bench_${TAG}_driver.err || tail -c 600 gpurun_out/bench_${TAG}_driver.err
 timeout -k 10 500 python bench.py > gpurun_out/bench_${TAG}_default.json 2> gpurun_out/bench_${TAG}_default.err || tail -c 600 gpurun_out/bench_${TAG}_default.err
 python - <<PY
