@@ -705,11 +705,6 @@ __device__ __forceinline__ void step_part(const V &v, const StepIO<SP> &io, cons
 // ---------------------------------------------------------------------------------------------------------------------
 // The phase functions (real functions, as in k_fused: each gets the register file to itself) and the kernel.
 // ---------------------------------------------------------------------------------------------------------------------
-// behind the row tables in device memory: the workspace block, then a copy of the model (rmpc_create)
-struct ArmBlock {
-  FusedWs F;
-  DevModel M;
-};
 
 // LDS of the wavefront (doubles): [ recursion work area | step N x (NV + NX) | hand-over words | gain images ]
 template <class C>

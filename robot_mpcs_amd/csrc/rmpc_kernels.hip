@@ -582,7 +582,7 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
   // single-variable rows two variables ahead of the arithmetic (var_load / var_compute below).  With the runtime
   // tables the requests stay where the arithmetic is, as before.
   // (the arms too, over the runtime tables: their sweep waits on memory for 63 % of its cycles -- 114 -> 110 us)
-  constexpr bool PIPE = V::SPEC || C::FKCURV;
+  constexpr bool PIPE = V::SPEC || C::FKCURV || std::is_same<V, GView>::value;
   double wuv[NU], wsv = 0.0, goalv[3] = {0, 0, 0}, wgoalv[3] = {0, 0, 0};
 #pragma unroll
   for (int j = 0; j < NU; j++) wuv[j] = P(v.off_wu() + j);
@@ -3622,6 +3622,11 @@ __global__ __launch_bounds__(kSweepBlock) void k_step(const DevModel M, const De
 // and the per-instance solver words through registers.  Results are bit-identical to the pass kernels: the
 // same sweep_body / step_body / inst_decide / riccati_recursion run, and the reductions use the same trees.
 // Blocks are independent and of one wavefront: the dispatcher backfills a CU as soon as a pair finishes.
+// the sweep and the step phase of the runtime-table models as real functions (GView); 0: inlined into k_fused (round 3)
+#ifndef RMPC_FUSED_CALLS
+#define RMPC_FUSED_CALLS 1
+#endif
+constexpr bool kFusedCalls = RMPC_FUSED_CALLS != 0;
 constexpr int kFusedStages = 32;   // stage stride of the per-instance layout = lanes per instance
 
 struct FusedWs {
@@ -3737,6 +3742,29 @@ __device__ __forceinline__ FusedCur fused_cur(const FusedWs &F, const size_t b, 
 // loads) -- and returns its results by value: with the SweepIO / StepIO structs as arguments and the partials behind
 // a reference, the argument and result traffic through scratch was 1.4 KB per lane and pass, more than the 0.9 KB
 // the sweep stores by design (round 2, L2 counters: 60 % of the fabric traffic of a launch were writes).
+// behind the row tables in device memory: the workspace block, then a copy of the model (rmpc_create)
+struct ArmBlock {
+  FusedWs F;
+  DevModel M;
+};
+// The view a phase FUNCTION reads the problem's structure through: a generated view is a set of constants; the runtime
+// tables come through uniform pointers in the constant address space (GView: tables in front of the pointer block,
+// the model's copy behind it), i.e. by scalar loads -- round 4: with that the sweep and the step phase of the models
+// WITHOUT a generated view (the boxer, the weighted / 2-joint chains) are real functions as well, each with the register
+// file to itself, and their requests can leave ahead of the arithmetic (PIPE in sweep_body).
+template <class V>
+__device__ __forceinline__ V call_view(const FusedWs *Fp) {
+  if constexpr (std::is_same<V, GView>::value) {
+    const unsigned long long a = (unsigned long long)Fp;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned long long u = ((unsigned long long)hi << 32) | lo;
+    typedef const __attribute__((address_space(4))) ArmBlock cArmBlock;
+    cArmBlock *const blk = (cArmBlock *)u;
+    return GView(&blk->M, (GView::cTables *)(u - sizeof(DevTables)));
+  } else {
+    return V{};
+  }
+}
 struct StepRes { double ap, ad, gp; };
 template <class C, class V, int FIRSTC, bool REC_LDS>
 __device__ __noinline__ RMPC_ONE_WAVE Partials fused_sweep_call(const FusedWs *Fp, const int N, const double dt, const int use_curv,
@@ -3766,7 +3794,7 @@ __device__ __noinline__ RMPC_ONE_WAVE Partials fused_sweep_call(const FusedWs *F
   }
   io.wl = Pw.pwl; io.wn = Pw.pwn; io.warm = warm;
   const SweepK sk = {N, dt, use_curv};
-  const V v{};
+  const V v = call_view<V>(Fp);
   Partials q = {0, 0, 0, 0, 0, 0, 0, 0, 1e300, 0};
   sweep_body<C, -1, RP, V, FIRSTC>(sk, v, io, k, FIRSTC != 0, nostep, alpha, adual, mu, q);
   return q;
@@ -3786,7 +3814,7 @@ __device__ __noinline__ RMPC_ONE_WAVE StepRes fused_step_call(const FusedWs *Fp,
   io.SS = S; io.loff = (unsigned)k;
   if constexpr (REC_LDS) { io.dz = slots + DZ_OFF; io.SSd = 1; io.loffd = (unsigned)(k * GS); }
   else { io.dz = Ps.pdz; io.SSd = S; io.loffd = (unsigned)k; }
-  const V v{};
+  const V v = call_view<V>(Fp);
   StepRes r = {1.0, 1.0, 0.0};
   step_body<C, RP, V>(v, io, k, mu, r.ap, r.ad, r.gp);
   return r;
@@ -3899,6 +3927,7 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1), di
   constexpr int LPI = kFusedStages;
   constexpr int IPW = 2;   // instances per wavefront
   constexpr int NX = C::NX, NV = C::NV;
+  using VC = typename std::conditional<V::SPEC, V, GView>::type;   // the view of the phase functions
   const V v(M, *Tp);
   const int half = threadIdx.x / LPI;
   const int k = threadIdx.x & (LPI - 1);       // stage of this lane; also its lane index inside the instance
@@ -4076,8 +4105,8 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1), di
       __attribute__((address_space(3))) SweepStepOut *const so = (__attribute__((address_space(3))) SweepStepOut *)&sres[half];
       if (v1) fused_sweep_step_call<C, V, 1>(so, Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, act && stage, nostep, fresh, s.ls, s.amin_p, s.amin_d, gphi_sum, s.mu, warm ? 1 : 0);
       else fused_sweep_step_call<C, V, 0>(so, Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, act && stage, nostep, fresh, s.ls, s.amin_p, s.amin_d, gphi_sum, s.mu, warm ? 1 : 0);
-    } else if constexpr (V::SPEC) {
-      // generated view: the sweep is a call (scalars in, partials out)
+    } else if constexpr (V::SPEC || kFusedCalls) {
+      // the sweep is a call (scalars in, partials out): a generated view, or the runtime tables through GView
       if (act && stage) {
         const bool nostep = first || (s.redo != 0);
         double alpha = 0.0, adual = 0.0;
@@ -4086,8 +4115,8 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1), di
           adual = s.amin_d;
         }
         const FusedWs *const Fp = (const FusedWs *)(Tp + 1);   // (the pointer block behind the row tables)
-        if (first) q = fused_sweep_call<C, V, 1, REC_LDS>(Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, nostep, alpha, adual, s.mu, warm ? 1 : 0);
-        else q = fused_sweep_call<C, V, 0, REC_LDS>(Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, nostep, alpha, adual, s.mu, warm ? 1 : 0);
+        if (first) q = fused_sweep_call<C, VC, 1, REC_LDS>(Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, nostep, alpha, adual, s.mu, warm ? 1 : 0);
+        else q = fused_sweep_call<C, VC, 0, REC_LDS>(Fp, M.N, M.dt, M.use_curv, b, s.cur, k, slots, nostep, alpha, adual, s.mu, warm ? 1 : 0);
       }
     } else if (act && stage) {
       const int cur = s.cur, nxt = cur ^ 1;
@@ -4181,10 +4210,10 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1), di
     // ---- step lengths of the new step -----------------------------------------------------------------
     const bool stepping = !MERGE2 && act && (s.status == ST_ACTIVE) && (s.newstep != 0);
     park();
-    if constexpr (V::SPEC) {
+    if constexpr (V::SPEC || kFusedCalls) {
       if (stepping && stage) {
         const FusedWs *const Fp = (const FusedWs *)(Tp + 1);
-        const StepRes sr = fused_step_call<C, V, REC_LDS>(Fp, b, s.cur, k, slots, s.mu);
+        const StepRes sr = fused_step_call<C, VC, REC_LDS>(Fp, b, s.cur, k, slots, s.mu);
         ap = sr.ap; ad = sr.ad; gp = sr.gp;
       }
     } else if (stepping && stage) {

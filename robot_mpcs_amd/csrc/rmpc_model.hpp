@@ -164,6 +164,18 @@ struct GView {
   __device__ __forceinline__ int slot_fb(int s) const { return T->slot_fb[s]; }
   __device__ __forceinline__ int slot_row_begin(int s) const { return T->slot_row_begin[s]; }
   __device__ __forceinline__ int nfkrows() const { return T->nfkrows; }
+  __device__ __forceinline__ int fk_row(int r) const { return T->fk_row[r]; }
+  __device__ __forceinline__ int fk_kind(int r) const { return T->fk_kind[r]; }
+  __device__ __forceinline__ int fk_obst(int r) const { return T->fk_obst[r]; }
+  __device__ __forceinline__ int fk_mod(int r) const { return T->fk_mod[r]; }
+  __device__ __forceinline__ int fk_first(int r) const { return T->fk_first[r]; }
+  __device__ __forceinline__ int fk_idx(int r) const { return T->fk_idx[r]; }
+  __device__ __forceinline__ int v_row(int j, int u) const { return T->v_row[j][u]; }
+  __device__ __forceinline__ int v_sgn(int j, int u) const { return T->v_sgn[j][u]; }
+  __device__ __forceinline__ int v_poff(int j, int u) const { return T->v_poff[j][u]; }
+  __device__ __forceinline__ int v_soft(int j, int u) const { return T->v_soft[j][u]; }
+  __device__ __forceinline__ int v_mod(int j, int u) const { return T->v_mod[j][u]; }
+  __device__ __forceinline__ int v_first(int j, int u) const { return T->v_first[j][u]; }
   __device__ __forceinline__ double v_val(int j, int u) const { return T->v_val[j][u]; }
   __device__ __forceinline__ int v_desc(int j, int u) const { return T->v_desc[j][u]; }
   __device__ __forceinline__ int fk_desc(int r) const { return T->fk_desc[r]; }
@@ -178,6 +190,8 @@ struct GView {
   __device__ __forceinline__ int off_goal() const { return M->off_goal; }
   __device__ __forceinline__ int off_wgoal() const { return M->off_wgoal; }
   __device__ __forceinline__ int off_wconstr() const { return M->off_wconstr; }
+  __device__ __forceinline__ int off_ws() const { return M->off_ws; }
+  __device__ __forceinline__ double dd_off(int f, int c) const { return M->dd_off[f][c]; }
   __device__ __forceinline__ int has_goal() const { return M->has_goal; }
   __device__ __forceinline__ int has_avoid() const { return M->has_avoid; }
   __device__ __forceinline__ int joint_type(int j) const { return M->joint_type[j]; }
