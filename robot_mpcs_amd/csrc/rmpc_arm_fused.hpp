@@ -36,15 +36,25 @@
 #define AIDXL(slot) ((unsigned)(slot) * (unsigned)kFusedStages + loffl)
 template <int P>
 __device__ __forceinline__ double part_sum(double v) {   // sum over the P aligned consecutive lanes of a stage
-  if constexpr (P >= 2) v += dpp_move<0xB1>(v);
-  if constexpr (P >= 4) v += dpp_move<0x4E>(v);
-  return v;
+  if constexpr (P == 3) {
+    // three parts (horizons of 21 stages at most: 63 of the 64 lanes carry a row instead of 40 at two parts): the
+    // group is no power of two, so the terms travel through the crossbar (ds_bpermute), and every lane adds them in
+    // the same order -- the three lanes of a stage must hold the same bits
+    const int base = ((int)threadIdx.x / 3) * 3;
+    const double v0 = __shfl(v, base, 64), v1 = __shfl(v, base + 1, 64), v2 = __shfl(v, base + 2, 64);
+    return (v0 + v1) + v2;
+  } else {
+    if constexpr (P >= 2) v += dpp_move<0xB1>(v);
+    if constexpr (P >= 4) v += dpp_move<0x4E>(v);
+    return v;
+  }
 }
 // v[p] for a per-lane p out of statically indexed values
 template <int P>
 __device__ __forceinline__ double part_pick(const int p, const double v0, const double v1, const double v2, const double v3) {
   if constexpr (P == 1) return v0;
   else if constexpr (P == 2) return (p & 1) ? v1 : v0;
+  else if constexpr (P == 3) return p == 0 ? v0 : (p == 1 ? v1 : v2);
   else return (p & 2) ? ((p & 1) ? v3 : v2) : ((p & 1) ? v1 : v0);
 }
 
@@ -745,7 +755,7 @@ __device__ __noinline__ void arm_sweep_call(__attribute__((address_space(3))) Ar
   load_block(F, &blkp->F);
   const int N = blk->M.N;
   const int lane = threadIdx.x;
-  const int p = lane & (P - 1), k = lane / P;
+  const int p = lane % P, k = lane / P;
   const bool live = k < N;
   const int ks = live ? k : N - 1;   // (lanes without a stage read the last stage's step: finite values, nothing stored)
   const size_t S = kFusedStages;

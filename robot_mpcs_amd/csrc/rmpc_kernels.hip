@@ -4746,7 +4746,7 @@ struct rmpc_handle {
   double prof_bytes[RMPC_NUM_KERNELS] = {0};     // accumulated algorithmic bytes of the profiled launches
   std::vector<int> h_hist;
   // debugging switches, read once at rmpc_create (never set by the product code)
-  bool env_no_migrate = false, env_dump_hist = false, env_no_order = false, env_no_cold_order = false;
+  bool env_no_migrate = false, env_dump_hist = false, env_no_order = false, env_no_cold_order = false, env_arm_two_parts = false;
 };
 
 // ---- per-variant launchers -----------------------------------------------------------------------------------------
@@ -4833,13 +4833,19 @@ int launch_fused_arm_t(rmpc_handle *h, int B, const double *d_xinit, const doubl
     const int use_order = (warm && !h->env_no_order) ? 1 : 0;
     // the grid is the chip (one wavefront per SIMD), the batch a queue its wavefronts drain
     const int grid = B < h->fused_grid ? B : h->fused_grid;
+    // parts per stage: three when the horizon leaves room for them (3 N <= 64 lanes), else two
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void *)k_fused_arm<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ArmLds<C>::TOTAL * 8);
+      (void)hipFuncSetAttribute((const void *)k_fused_arm<C, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, ArmLds<C>::TOTAL * 8);
       attr_set = true;
     }
-    hipLaunchKernelGGL((k_fused_arm<C, 2>), dim3(grid), dim3(64), ArmLds<C>::TOTAL * 8, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
-                       d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm, use_order);
+    if (3 * h->M.N <= 64 && !h->env_arm_two_parts)
+      hipLaunchKernelGGL((k_fused_arm<C, 3>), dim3(grid), dim3(64), ArmLds<C>::TOTAL * 8, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
+                         d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm, use_order);
+    else
+      hipLaunchKernelGGL((k_fused_arm<C, 2>), dim3(grid), dim3(64), ArmLds<C>::TOTAL * 8, st, h->M, h->d_T, h->F, B, d_xinit, d_x0,
+                         d_params, d_zout, d_exit, d_iters, d_kkt, d_obj, cap, warm, use_order);
     return 0;
   } else {
     return fail("no fused arm kernel for this model");
@@ -5789,6 +5795,7 @@ int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
   if (e != hipSuccess) { rmpc_destroy(h); return fail(std::string("stream / pinned word: ") + hipGetErrorString(e)); }
   if (const char *rl = getenv("RMPC_RIC_LANE")) h->ric_lane = atoi(rl);   // (development switch)
   h->env_no_migrate = getenv("RMPC_NO_MIGRATE") != nullptr;
+  h->env_arm_two_parts = getenv("RMPC_ARM_TWO_PARTS") != nullptr;   // (development switch: k_fused_arm with two parts per stage at every horizon)
   h->env_no_order = getenv("RMPC_NO_ORDER") != nullptr;   // (development switch: fused launches in index order)
   h->env_no_cold_order = getenv("RMPC_NO_COLD_ORDER") != nullptr;   // (development switch: cold fused launches in index order)
   h->env_dump_hist = getenv("RMPC_DUMP_HIST") != nullptr;

@@ -82,6 +82,28 @@ def test_arm_pass_kernels_match_oracle(rt, name, B, seed, monkeypatch):
     _check_plan(gpu, cpu, sc.desc["nx"] + sc.desc["ns"])
 
 
+@pytest.mark.parametrize("name,B,seed,kw", [("cfg4", 96, 75, {}), ("chain5", 48, 76, {}), ("chain6", 48, 77, {}), ("cfg4", 32, 79, {"time_horizon": 21}), ("cfg4", 32, 80, {"time_horizon": 22})])
+def test_fused_arm_two_parts_per_stage_match_oracle(rt, name, B, seed, kw, monkeypatch):
+    """k_fused_arm deals a stage's slots and joints to THREE lanes when the horizon leaves room (3 N <= 64: 63 of the 64
+    lanes carry rows at N = 21, 60 at BASELINE's N = 20) and to two otherwise.  The two-part kernel forced at short
+    horizons (RMPC_ARM_TWO_PARTS=1, read at rmpc_create) against the oracle, and both dealings against each other: the
+    same flags and iteration counts, plans to the parity tolerance (the parts' partial sums are added in another order)."""
+    sc = rt["make_scenario"](name, B=B, seed=seed, **kw)
+    cpu = rt["Oracle"](sc.desc).solve_batch(sc.xinit, sc.x0, sc.params)
+    s3 = rt["Solver"](sc.desc, max_batch=B)
+    assert s3.is_fused()
+    three = s3.solve(sc.xinit, sc.x0, sc.params)
+    s3.close()
+    monkeypatch.setenv("RMPC_ARM_TWO_PARTS", "1")
+    s2 = rt["Solver"](sc.desc, max_batch=B)
+    assert s2.is_fused()
+    two = s2.solve(sc.xinit, sc.x0, sc.params)
+    s2.close()
+    _check_plan(two, cpu, sc.desc["nx"] + sc.desc["ns"])
+    _check_plan(three, cpu, sc.desc["nx"] + sc.desc["ns"])
+    assert np.array_equal(two["exitflag"], three["exitflag"]) and np.array_equal(two["iters"], three["iters"])
+
+
 @pytest.mark.parametrize("name,B,seed", [("cfg2", 192, 81), ("chain2", 96, 82)])
 def test_lane_per_instance_recursion_matches_oracle(rt, name, B, seed, monkeypatch):
     """k_riccati_lane (one lane per instance: the default recursion of the pass kernels for lists of at least 16384
