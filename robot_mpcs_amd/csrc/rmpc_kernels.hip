@@ -1665,6 +1665,12 @@ __device__ __forceinline__ double dpp_move(const double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
+// sum over the 4 lanes of a quad; every lane of the quad ends with the total
+__device__ __forceinline__ double dpp_sum4(double v) {
+  v += dpp_move<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_move<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  return v;
+}
 // sum over the 8 aligned consecutive lanes a lane belongs to; every lane of the group ends with the total
 __device__ __forceinline__ double dpp_sum8(double v) {
   v += dpp_move<0xB1>(v);    // quad_perm [1, 0, 3, 2]
@@ -1816,7 +1822,216 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
   // before the first use (one wait per phase instead of one per entry), nothing is predicated except the
   // stores, and the cost-to-go products of a lane's q entry are formed by the lane itself instead of going
   // through another LDS exchange: three waits per stage instead of about twenty.
-  constexpr bool FAST = SLOTS && !DD;
+  // ---- fused kernel, holonomic chain without slack, n <= 3 (the point robot): Schur-complement form on the slots --------
+  // Round 4.  At four wavefronts per CU the recursion of k_fused is bound by the LDS: the path below it (kept for the
+  // chains with the slack variable) reads 78 doubles per lane and backward stage and 24 per forward stage; this one
+  // reads 37 and 17 -- the block form of the arms' path (riccati_recursion's ARMB) at half-wavefront width:
+  //   A  lane (i, j) of an n x n grid (8-lane groups) reads S, T, T', V of the cost-to-go once and forms the seven
+  //      block entries of [A|B]^T P [A|B]; its eight record entries come from the stage's slot one stage ahead;
+  //      g = P rc + p by DPP sums over the group, lanes j = 0, 1, 2 finish the gradient entries q_i, v_i, u_i;
+  //   B  Cholesky of Quu in every lane, Y = L^-1 [Qux | qu] (a column per lane), the gains K = -L^-T Y behind it;
+  //   C  [P | p] = [Qxx | qx] - Y^T [Y | y]: an entry per lane and turn, (i, j) and (j, i) the same products in the
+  //      same order (Qxx is formed symmetrically): symmetric without the 0.5 (a + a^T) of the gain form.
+  // The rollout forms dw, nu+ and dx+ from dx alone with one role per lane (one row of the image per lane).
+#ifdef RMPC_NO_FASTB
+  constexpr bool FASTB = false;
+#else
+  constexpr bool FASTB = SLOTS && !DD && NS == 0 && NQ <= 3 && LPI == 32;
+#endif
+  if constexpr (FASTB) {
+    constexpr int n = NQ;
+    constexpr int OFF_KFF = NW * NX, OFF_PT = OFF_KFF + NW, OFF_P = OFF_PT + NP2, OFF_RC = OFF_P + NX;
+    static_assert(NW == n && NX == 2 * n && NX + 1 <= 8, "point-robot path: holonomic chain without slack, n <= 3");
+    static_assert(20 * NW + 48 <= RicLds<C, LPI>::LDSW, "point-robot path: work area");
+    // work area: [Qux | qu] (NW rows of 8) | Quu (NW rows of 4) | Y (NW rows of 8) | dx (2 x 8) | a word per idle lane
+    ldouble *const aQux = img, *const aQuu = aQux + 8 * NW, *const aY = aQuu + 4 * NW, *const adx = aY + 8 * NW,
+                 *const adum = adx + 16;
+    ldouble *const dummy = adum + lane;
+    // -- lane (gi, gj), block position (ii, jj): the lane keeps its entries S, T, T', V of the cost-to-go (and p_i in
+    //    lanes gj = 0, p_{n+i} in lanes gj = 1) in registers from stage to stage -----------------------------------------
+    const int gi = lane >> 3, gj = lane & 7;
+    const bool gval = gi < n, gon = gval && gj < n;
+    const int ii = gval ? gi : 0, jj = gj < n ? gj : 0;
+    const bool gdiag = gon && ii == jj;
+    const int qlo = ii < jj ? ii : jj, qhi = ii < jj ? jj : ii;
+    const int tq = qlo * n - qlo * (qlo - 1) / 2 + (qhi - qlo);
+    const int jme = gj == 0 ? ii : (gj == 1 ? n + ii : (gj == 2 ? 2 * n + ii : 0));   // gradient entry of lanes gj <= 2
+    const double gc1 = gj == 0 ? 1.0 : (gj == 1 ? h : h2), gc2 = gj == 0 ? 0.0 : (gj == 1 ? 1.0 : h);
+    int ro[8];   // record entries of this lane
+    ro[0] = C::R_Q + tq; ro[1] = C::R_C + tq; ro[2] = C::R_DG + ii; ro[3] = C::R_DG + n + ii;
+    ro[4] = C::R_RC + jj; ro[5] = C::R_RC + n + jj; ro[6] = C::R_Q0 + jme; ro[7] = C::R_Q1 + jme;
+    ldouble *const dUq = gon ? aQux + ii * 8 + jj : dummy, *const dUv = gon ? aQux + ii * 8 + n + jj : dummy,
+                 *const dUu = gon ? aQuu + ii * 4 + jj : dummy;
+    ldouble *const dqu = (gval && gj == 2) ? aQux + ii * 8 + NX : dummy;   // gradient of u_i (q_i, v_i stay in registers)
+    const bool rcw = lane < n;   // lanes (0, jj) put the defect of the stage into the image
+    const int myrow = gj == 1 ? n + ii : ii;   // row of [P | p] whose p entry this lane forms (lanes gj = 0, 1)
+    // where the lane's entries of the new cost-to-go go in the image of the stage (packed upper triangle; p)
+    const int sS = (gon && ii <= jj) ? OFF_PT + tri(ii, jj) : -1, sT = gon ? OFF_PT + tri(ii, n + jj) : -1,
+              sV = (gon && ii <= jj) ? OFF_PT + tri(n + ii, n + jj) : -1, sp_ = (gval && gj <= 1) ? OFF_P + myrow : -1;
+    // -- phase B: gain column of this lane (NX: the gradient column) ---------------------------------------------------
+    const int bc = lane <= NX ? lane : 0;
+    ldouble *const dY = lane <= NX ? aY + bc : dummy;
+    const int ystr = lane <= NX ? 8 : 0;
+    const int koff = lane < NX ? lane : (lane == NX ? OFF_KFF : -1), kstr = lane < NX ? NX : (lane == NX ? 1 : 0);
+    double rn[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) rn[u] = slots[(size_t)(N - 1) * GS + ro[u]];
+    double S = 0.0, T = 0.0, U = 0.0, V = 0.0, p1 = 0.0, p2 = 0.0;   // P = 0, p = 0 behind the last stage
+    WSYNC();
+    RST_DECL();
+    for (int k = N - 1; k >= 0; k--) {
+      ldouble *const slot = slots + (size_t)k * GS;   // record of stage k (in registers by now); becomes its image
+      double rc_[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) rc_[u] = rn[u];
+      {
+        const int kn = k > 0 ? k - 1 : 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) rn[u] = slots[(size_t)kn * GS + ro[u]];   // arrives while this stage is computed
+      }
+      // ---- phase A: the blocks of [A|B]^T P [A|B] at (ii, jj); Qxx stays in registers --------------------------------
+      const double rcj = gj < n ? rc_[4] : 0.0, rcnj = gj < n ? rc_[5] : 0.0;
+      const double tv = h * S + T, tu = h2 * S + h * T, bv = h * U + V, bu = h2 * U + h * V;
+      const double qq = S + (rc_[0] - cwt * rc_[1]);
+      const double vq = h * S + U;
+      const double vv = (h * (h * S + (T + U)) + V) + (gdiag ? rc_[2] : 0.0);
+      const double uq = h2 * S + h * U, uv = h2 * tv + h * bv;
+      const double uu = (h2 * tu + h * bu) + (gdiag ? rc_[3] : 0.0);
+      *dUq = uq; *dUv = uv; *dUu = uu;
+      // g = P rc + p: the group's partial products, summed over its lanes (gj < n <= 3: one quad)
+      const double g1 = p1 + dpp_sum4(S * rcj + T * rcnj), g2 = p2 + dpp_sum4(U * rcj + V * rcnj);
+      const double gme = (rc_[6] - mu * rc_[7]) + (gc1 * g1 + gc2 * g2);   // gradient entry q_i / v_i / u_i (gj = 0, 1, 2)
+      *dqu = gme;
+      *(rcw ? slot + OFF_RC + lane : dummy) = rc_[4];
+      *(rcw ? slot + OFF_RC + n + lane : dummy) = rc_[5];
+      WSYNC();
+      RST(1);
+      // ---- phase B: Cholesky of Quu (every lane), Y = L^-1 [Qux | qu] (one column per lane) ------------------------------
+      {
+        double qw[NW][NW], colv[NW];
+#pragma unroll
+        for (int j = 0; j < NW; j++)
+#pragma unroll
+          for (int i = j; i < NW; i++) qw[i][j] = aQuu[i * 4 + j];
+#pragma unroll
+        for (int i = 0; i < NW; i++) colv[i] = aQux[i * 8 + bc];
+        __builtin_amdgcn_sched_barrier(0);
+        double L[NW][NW], invd[NW];
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+          double dg = qw[j][j];
+#pragma unroll
+          for (int l = 0; l < j; l++) dg -= L[j][l] * L[j][l];
+          if (!(dg > 0.0)) chol_ok = false;
+          double inv = __builtin_amdgcn_rsq(dg);
+          inv = inv * (1.5 - 0.5 * dg * inv * inv);
+          inv = inv * (1.5 - 0.5 * dg * inv * inv);
+          L[j][j] = dg * inv;
+          invd[j] = inv;
+#pragma unroll
+          for (int i = j + 1; i < NW; i++) {
+            double sacc = qw[i][j];
+#pragma unroll
+            for (int l = 0; l < j; l++) sacc -= L[i][l] * L[j][l];
+            L[i][j] = sacc * inv;
+          }
+        }
+        double y[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+          double sacc = colv[i];
+#pragma unroll
+          for (int l = 0; l < i; l++) sacc -= L[i][l] * y[l];
+          y[i] = sacc * invd[i];
+          dY[i * ystr] = y[i];
+        }
+        WSYNC();
+        RST(3);
+        // ---- phase C: [P | p] = [Qxx | qx] - Y^T [Y | y] at the lane's own block position: the next stage's phase A
+        //      starts from registers (no store of P, no ordering point, no read-back) ---------------------------------------
+        double yiq[NW], yiv[NW], yjq[NW], yjv[NW], yg[NW];
+#pragma unroll
+        for (int l = 0; l < NW; l++) {
+          yiq[l] = aY[l * 8 + ii]; yiv[l] = aY[l * 8 + n + ii]; yjq[l] = aY[l * 8 + jj]; yjv[l] = aY[l * 8 + n + jj];
+          yg[l] = aY[l * 8 + NX];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (while the operands arrive: the gains K = -L^-T Y of this lane's column, for the rollout only)
+        double x[NW];
+#pragma unroll
+        for (int i = NW - 1; i >= 0; i--) {
+          double sacc = y[i];
+#pragma unroll
+          for (int l = i + 1; l < NW; l++) sacc -= L[l][i] * x[l];
+          x[i] = sacc * invd[i];
+        }
+        ldouble *const kd = koff >= 0 ? slot + koff : dummy;
+#pragma unroll
+        for (int i = 0; i < NW; i++) kd[i * kstr] = -x[i];
+        double sn = qq, tn_ = tv, un = vq, vn = vv, pn = gme;
+#pragma unroll
+        for (int l = 0; l < NW; l++) {
+          sn -= yiq[l] * yjq[l]; tn_ -= yiq[l] * yjv[l]; un -= yiv[l] * yjq[l]; vn -= yiv[l] * yjv[l];
+          pn -= (gj == 1 ? yiv[l] : yiq[l]) * yg[l];
+        }
+        S = sn; T = tn_; U = un; V = vn;
+        p1 = dpp_move<0x00>(pn);   // quad_perm [0, 0, 0, 0]: p_i from lane gj = 0 of the quad
+        p2 = dpp_move<0x55>(pn);   // quad_perm [1, 1, 1, 1]: p_{n+i} from lane gj = 1
+        *(sS >= 0 ? slot + sS : dummy) = sn;
+        *(sT >= 0 ? slot + sT : dummy) = tn_;
+        *(sV >= 0 ? slot + sV : dummy) = vn;
+        *(sp_ >= 0 ? slot + sp_ : dummy) = pn;
+      }
+      RST(4);
+    }
+    WSYNC();
+    if (!chol_ok) return false;
+    // ---- rollout: dw = kff + K dx, nu+ = p + P dx, dx+ = rc + [A|B][dx; dw], one ordering point per stage ---------------
+    const bool fA = lane < NW, fB = lane >= NW && lane < NW + NX, fC = lane >= NW + NX && lane < NW + 2 * NX;
+    const int fi = fA ? lane : (fB ? lane - NW : (fC ? lane - NW - NX : 0));   // entry of dw / nu+ / dx+
+    const int fw = fC ? (fi < n ? fi : fi - n) : fi;                             // the entry of dw a dx+ lane needs
+    const int foff = fB ? OFF_P + fi : OFF_KFF + fw;
+    int frow[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) frow[j] = fB ? OFF_PT + tri(fi, j) : fw * NX + j;
+    const int fx1 = fi < n ? n + fi : fi;
+    const double fca = fi < n ? h : 0.0, fcb = fi < n ? h2 : h;
+    const int dzslot = fA ? NX + lane : fi;
+    // (dx through the crossbar -- ds_bpermute, no store / ordering point / read-back, the image rows requested a stage
+    //  ahead -- was measured slower: 16 crossbar instructions per stage cost more LDS issue than the exchange saves,
+    //  2.85 -> 2.75 M solves/s on cfg2 with four batches in flight)
+    if (lane < 16) adx[lane] = 0.0;
+    for (int k = 0; k < N; k++) {
+      const ldouble *const im = slots + (size_t)k * GS;
+      const ldouble *const dxc = adx + 8 * (k & 1);
+      ldouble *const dxn = adx + 8 * ((k & 1) ^ 1);
+      // (the lane's row of the image does not depend on dx: requested before the ordering point, it arrives with it)
+      double rowv[NX];
+#pragma unroll
+      for (int j = 0; j < NX; j++) rowv[j] = im[frow[j]];
+      double sacc = im[foff];
+      const double rcv = im[OFF_RC + fi];
+      WSYNC();
+      double dxv[NX];
+#pragma unroll
+      for (int j = 0; j < NX; j++) dxv[j] = dxc[j];
+      const double d0 = dxc[fi], d1 = dxc[fx1];
+      __builtin_amdgcn_sched_barrier(0);   // (the image of the stage is read before its step is stored over it)
+#pragma unroll
+      for (int j = 0; j < NX; j++) sacc += rowv[j] * dxv[j];
+      *((fA || fC) ? so.dz + dzslot + (size_t)k * GS : dummy) = fA ? sacc : d0;
+      *((fB && k >= 1) ? so.nunew + fi + (size_t)k * GS : dummy) = sacc;
+      double sx = rcv;
+      sx += d0;
+      sx += fca * d1;
+      sx += fcb * sacc;
+      *((fC && k < N - 1) ? dxn + fi : dummy) = sx;
+      RST(6);
+    }
+    RST_FLUSH();
+    return true;
+  }
+  constexpr bool FAST = SLOTS && !DD && !FASTB;
   // the arms' cost-to-go update on the matrix cores (v_mfma_f64_16x16x4_f64): one wavefront per instance, a state of
   // 9 .. 15 entries (one tile with the gradient column), at most 8 inputs (two k-steps)
   constexpr bool MFMA_P = !DD && !SLOTS && LPI == 64 && NX > 8 && NX < 16 && NW <= 8;
