@@ -839,22 +839,32 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
   using Ord = SweepOrder<C, EARLY>;
   // positions [P0, P1) of the order; PIPE: the requests of a variable are issued two variables ahead (the first two
   // of the range by the caller when PRE is set)
-  VarBuf vring[PIPE ? 3 : 1];
+  // (PD: how many variables ahead.  Two: the boxer over the runtime tables at three and four -- a round trip to the
+  //  instance's block is 2 - 3 us with the chip full, the rows of a variable 0.5 us -- spills 428 / 556 B per lane instead
+  //  of 296 and loses 4 - 7 %: 0.68 -> 0.64 M solves/s with four batches in flight)
+#ifdef RMPC_PIPE_DEPTH
+  constexpr int PD = RMPC_PIPE_DEPTH;
+#else
+  constexpr int PD = 2;
+#endif
+  VarBuf vring[PIPE ? PD + 1 : 1];
   auto run_vars = [&](auto p0c, auto p1c, auto finc, auto prec) __attribute__((always_inline)) {
     constexpr int P0 = decltype(p0c)::value, P1 = decltype(p1c)::value;
     constexpr bool FIN = decltype(finc)::value, PRE = decltype(prec)::value;
     if constexpr (P1 > P0) {
       if constexpr (PIPE && !PRE) {
-        var_load(std::integral_constant<int, Ord::at(P0)>{}, vring[0]);
-        if constexpr (P0 + 1 < P1) var_load(std::integral_constant<int, Ord::at(P0 + 1 < P1 ? P0 + 1 : P0)>{}, vring[1]);
+        for_range<0, PD>([&](auto dc) __attribute__((always_inline)) {
+          constexpr int d = decltype(dc)::value;
+          if constexpr (P0 + d < P1) var_load(std::integral_constant<int, Ord::at(P0 + d < P1 ? P0 + d : P0)>{}, vring[d]);
+        });
       }
       for_range<P0, P1>([&](auto pc) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value;
         constexpr int j = Ord::at(p);
         if constexpr (PIPE) {
-          if constexpr (p + 2 < P1) var_load(std::integral_constant<int, Ord::at(p + 2 < P1 ? p + 2 : p)>{}, vring[(p + 2 - P0) % 3]);
+          if constexpr (p + PD < P1) var_load(std::integral_constant<int, Ord::at(p + PD < P1 ? p + PD : p)>{}, vring[(p + PD - P0) % (PD + 1)]);
           __builtin_amdgcn_sched_barrier(0);
-          var_compute(std::integral_constant<int, j>{}, vring[(p - P0) % 3]);
+          var_compute(std::integral_constant<int, j>{}, vring[(p - P0) % (PD + 1)]);
         } else {
           var_load(std::integral_constant<int, j>{}, vring[0]);
           var_compute(std::integral_constant<int, j>{}, vring[0]);
@@ -866,11 +876,13 @@ __device__ __forceinline__ void sweep_body(const SweepK M, const V &v, const Swe
   using TrueT = std::integral_constant<bool, true>;
   using FalseT = std::integral_constant<bool, false>;
   run_vars(std::integral_constant<int, 0>{}, std::integral_constant<int, Ord::NFIRST>{}, TrueT{}, FalseT{});
-  // (no variable goes first: the requests of the first two variables leave before the kinematics)
+  // (no variable goes first: the requests of the first PD variables leave before the kinematics)
   constexpr bool PRE2 = PIPE && (Ord::NFIRST == 0);
   if constexpr (PRE2) {
-    var_load(std::integral_constant<int, Ord::at(0)>{}, vring[0]);
-    if constexpr (NV > 1) var_load(std::integral_constant<int, Ord::at(NV > 1 ? 1 : 0)>{}, vring[1]);
+    for_range<0, PD>([&](auto dc) __attribute__((always_inline)) {
+      constexpr int d = decltype(dc)::value;
+      if constexpr (d < NV) var_load(std::integral_constant<int, Ord::at(d < NV ? d : 0)>{}, vring[d]);
+    });
   }
 
   // ---- kinematics, GoalReaching and the FK rows, slot by slot -------------------
