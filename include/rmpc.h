@@ -45,8 +45,10 @@ extern "C" {
  * 0.1.5 (105): rmpc_is_async, rmpc_retarget_device (round 3; the macro was not bumped then).
  * 0.2.0 (200): rmpc_retarget_device takes an rmpc_retarget struct (failed solves keep their state, settled robots,
  *              64-bit counters: NOT source compatible with 0.1.5), rmpc_advance_obstacles_device; rmpc_is_fused is 1
- *              for the arms with 5 .. 7 joints as well (k_fused_arm). */
-#define RMPC_VERSION 200
+ *              for the arms with 5 .. 7 joints as well (k_fused_arm).
+ * 0.2.1 (201): RMPC_MOD_ROWS -- constraint modules given as row descriptions (rmpc_desc grows by the xrow_* arrays at
+ *              its end; a descriptor of the 0.2.0 size is still accepted and has no such rows). */
+#define RMPC_VERSION 201
 
 #define RMPC_MAX_JOINTS 8
 #define RMPC_MAX_LINKS 8
@@ -65,6 +67,19 @@ extern "C" {
 #define RMPC_MOD_JOINTLIMIT 3
 #define RMPC_MOD_VELLIMIT 4
 #define RMPC_MOD_INPUTLIMIT 5
+/* A user-defined module (a YAML constraint name that is none of the six classes above): its rows are described one by
+ * one in rmpc_desc::xrow_* -- variants of the six kinds (other frames, other joints, own parameter entries) need no
+ * rebuild of the library.  The reference resolves such a name to a user class by getattr
+ * (robotmpcs/models/inequalities/InequalityManager.py:17-21) and lets CasADi differentiate it; here the row kinds the
+ * kernels evaluate are the vocabulary. */
+#define RMPC_MOD_ROWS 6
+#define RMPC_MAX_XROWS 32
+/* row kinds of RMPC_MOD_ROWS (value h >= 0; r_body = the model's off_r_body entry) */
+#define RMPC_ROW_RADIAL 0 /* ||fk_a(q) - c|| - r - r_body, (c, r) = 4 parameters at xrow_poff (RadialConstraints.py:6-23) */
+#define RMPC_ROW_LINEAR 1 /* |n . fk_a(q) + d| / ||n|| - r_body, (n, d) = 4 parameters at xrow_poff (LinearConstraints.py:8-40) */
+#define RMPC_ROW_SELF 2   /* ||fk_a(q) - fk_b(q)|| - 2 r_body (SelfCollisionAvoidanceConstraints.py:8-27) */
+#define RMPC_ROW_VAR 3    /* b = +1: z_a - limit, b = -1: limit - z_a, limit = the parameter at xrow_poff
+                             (JointLimitConstraints.py:8-31, InputLimitConstraints.py:7-29) */
 
 #define RMPC_JOINT_FIXED 0
 #define RMPC_JOINT_REVOLUTE 1
@@ -108,6 +123,17 @@ typedef struct rmpc_desc {
   int32_t ls_max;       /* step halvings allowed in one line search (default 25); an instance that exhausts them
                            stops with exitflag -8 and its current iterate.  Small values bound the number of passes
                            of a real-time solve (examples/fleet_loop.py) */
+  /* ---- 0.2.1: rows of the RMPC_MOD_ROWS modules, in row order; xrow_mod = index into module_kind.  The rows of one
+   * module must all be on states (RADIAL / LINEAR / SELF, VAR with a < nx) or all on inputs (VAR with a >= nx + ns): the
+   * stage-1 neutralisation and the inverse-barrier objective are per module (InequalityManager.py:25-33).  RADIAL and
+   * LINEAR rows address their parameters as entries of the obstacle / plane lists: xrow_poff - off_obst (off_lin) must
+   * be a multiple of 4 in [0, 252] (an absent list starts at the first such row). */
+  int32_t n_xrows;
+  int32_t xrow_mod[RMPC_MAX_XROWS];
+  int32_t xrow_kind[RMPC_MAX_XROWS];
+  int32_t xrow_a[RMPC_MAX_XROWS];
+  int32_t xrow_b[RMPC_MAX_XROWS];
+  int32_t xrow_poff[RMPC_MAX_XROWS];
 } rmpc_desc;
 
 typedef struct rmpc_handle rmpc_handle;

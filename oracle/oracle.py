@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "librmpc_oracle.so")
 
 MAX_JOINTS, MAX_LINKS, MAX_PAIRS, MAX_MODULES, NV_MAX = 8, 8, 4, 8, 24
+MAX_XROWS = 32
 TRACE_W = 8
 
 
@@ -43,6 +44,9 @@ class OrcDesc(C.Structure):
         ("tol_stat", C.c_double), ("tol_eq", C.c_double), ("tol_ineq", C.c_double), ("tol_comp", C.c_double),
         ("mu0", C.c_double),
         ("acc_iters", C.c_int32), ("acc_obj_tol", C.c_double), ("ls_max", C.c_int32),
+        # rows of the row-described modules (include/rmpc.h RMPC_MOD_ROWS)
+        ("n_xrows", C.c_int32), ("xrow_mod", C.c_int32 * MAX_XROWS), ("xrow_kind", C.c_int32 * MAX_XROWS),
+        ("xrow_a", C.c_int32 * MAX_XROWS), ("xrow_b", C.c_int32 * MAX_XROWS), ("xrow_poff", C.c_int32 * MAX_XROWS),
     ]
 
 
@@ -137,6 +141,12 @@ def make_desc(d: dict) -> OrcDesc:
     o.mu0 = float(opt.get("mu0", 1.0))
     o.acc_iters = int(opt.get("acc_iters", 8)); o.acc_obj_tol = float(opt.get("acc_obj_tol", 1e-8))
     o.ls_max = int(opt.get("ls_max", 25))
+    xrows = d.get("xrows", [])
+    if len(xrows) > MAX_XROWS:
+        raise ValueError("more than %d described rows" % MAX_XROWS)
+    o.n_xrows = len(xrows)
+    for i, r in enumerate(xrows):
+        o.xrow_mod[i], o.xrow_kind[i], o.xrow_a[i], o.xrow_b[i], o.xrow_poff[i] = (int(v) for v in r)
     return o
 
 

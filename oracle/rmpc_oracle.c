@@ -245,14 +245,19 @@ int orc_dynamics(const orc_desc *d, const double *x, const double *u, double *xn
 /* ------------------------------------------------------------------ */
 /* rows                                                                 */
 /* ------------------------------------------------------------------ */
-static int module_rows(const orc_desc *d, int kind) {
-  switch (kind) {
+static int module_rows(const orc_desc *d, int mi) {
+  switch (d->module_kind[mi]) {
     case ORC_MOD_RADIAL: return d->nobst * d->n_links;          /* RadialConstraints.py:9 */
     case ORC_MOD_LINEAR: return d->nobst * d->n_links;          /* LinearConstraints.py:13 */
     case ORC_MOD_SELFCOLLISION: return d->n_pairs;              /* SelfCollision...py:13 */
     case ORC_MOD_JOINTLIMIT: return 2 * d->n;                   /* JointLimitConstraints.py:10 */
     case ORC_MOD_VELLIMIT: return 4;                            /* VelLimitConstraints.py:28-31 (4 rows; _n_ineq=2 is a bug) */
     case ORC_MOD_INPUTLIMIT: return 2 * d->nu;                  /* InputLimitConstraints.py:7 */
+    case ORC_MOD_ROWS: {                                        /* a user class of InequalityManager.py:17-21, as rows */
+      int c = 0;
+      for (int r = 0; r < d->n_xrows; r++) c += d->xrow_mod[r] == mi;
+      return c;
+    }
   }
   return -1;
 }
@@ -260,7 +265,7 @@ static int module_rows(const orc_desc *d, int kind) {
 int orc_num_rows(const orc_desc *d, int *nh_out, int *m_out) {
   int nh = 0;
   for (int i = 0; i < d->n_modules; i++) {
-    int r = module_rows(d, d->module_kind[i]);
+    int r = module_rows(d, i);
     if (r < 0) return -1;
     nh += r;
   }
@@ -390,6 +395,7 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
   for (int mi = 0; mi < d->n_modules; mi++) {
     const int kind = d->module_kind[mi];
     const int row0 = row;
+    int xrows_on_u = 0;   /* (ORC_MOD_ROWS) the module's rows are on inputs */
     if (kind == ORC_MOD_RADIAL) {
       /* mpcBase.py:82-101: links outer, obstacles inner */
       const double rb = p[d->off_r_body];
@@ -504,10 +510,88 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
         if (want) Jg[row * nv + idx] = -1.0;
         row++;
       }
+    } else if (kind == ORC_MOD_ROWS) {
+      /* a module given as row descriptions (orc_desc::xrow_*): the arithmetic of the row kinds above, one row each */
+      for (int xr = 0; xr < d->n_xrows; xr++) {
+        if (d->xrow_mod[xr] != mi) continue;
+        const int a0 = d->xrow_a[xr], b0 = d->xrow_b[xr], po = d->xrow_poff[xr];
+        if (d->xrow_kind[xr] == ORC_ROW_RADIAL) {
+          const double rb = p[d->off_r_body];
+          const int fr = a0;
+          NEED_FK(fr);
+          const double *ob = p + po;
+          double dv[3] = {fpos[fr][0] - ob[0], fpos[fr][1] - ob[1], fpos[fr][2] - ob[2]};
+          double dist = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+          g[row] = dist - ob[3] - rb;
+          if (want) {
+            for (int a = 0; a < n; a++)
+              Jg[row * nv + a] = (dv[0] * fJ[fr][0 * n + a] + dv[1] * fJ[fr][1 * n + a] + dv[2] * fJ[fr][2 * n + a]) / dist;
+            for (int a = 0; a < n; a++)
+              for (int bb = 0; bb < n; bb++) {
+                double jj = fJ[fr][0 * n + a] * fJ[fr][0 * n + bb] + fJ[fr][1 * n + a] * fJ[fr][1 * n + bb] + fJ[fr][2 * n + a] * fJ[fr][2 * n + bb];
+                tl_C[row][a * n + bb] = (jj - Jg[row * nv + a] * Jg[row * nv + bb]) / dist;
+              }
+            if (with_fk_curv(d)) {
+              const double F[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist};
+              orc_fk_curv(d, q, fr, F, tl_C[row]);
+            }
+          }
+        } else if (d->xrow_kind[xr] == ORC_ROW_LINEAR) {
+          const double rb = p[d->off_r_body];
+          const int fr = a0;
+          NEED_FK(fr);
+          const double *pl = p + po;
+          double nn = sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
+          double sd = pl[0] * fpos[fr][0] + pl[1] * fpos[fr][1] + pl[2] * fpos[fr][2] + pl[3];
+          double sg = sd < 0 ? -1.0 : 1.0;
+          g[row] = fabs(sd) / nn - rb;
+          if (want)
+            for (int a = 0; a < n; a++)
+              Jg[row * nv + a] = sg * (pl[0] * fJ[fr][0 * n + a] + pl[1] * fJ[fr][1 * n + a] + pl[2] * fJ[fr][2 * n + a]) / nn;
+          if (want && with_fk_curv(d)) {
+            const double F[3] = {sg * pl[0] / nn, sg * pl[1] / nn, sg * pl[2] / nn};
+            orc_fk_curv(d, q, fr, F, tl_C[row]);
+          }
+        } else if (d->xrow_kind[xr] == ORC_ROW_SELF) {
+          const double rb = p[d->off_r_body];
+          const int fa = a0, fb = b0;
+          NEED_FK(fa);
+          NEED_FK(fb);
+          double dv[3] = {fpos[fa][0] - fpos[fb][0], fpos[fa][1] - fpos[fb][1], fpos[fa][2] - fpos[fb][2]};
+          double dist = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+          g[row] = dist - 2.0 * rb;
+          if (want) {
+            for (int a = 0; a < n; a++) {
+              double s3 = 0;
+              for (int i = 0; i < 3; i++) s3 += dv[i] * (fJ[fa][i * n + a] - fJ[fb][i * n + a]);
+              Jg[row * nv + a] = s3 / dist;
+            }
+            for (int a = 0; a < n; a++)
+              for (int bb = 0; bb < n; bb++) {
+                double jj = 0;
+                for (int i = 0; i < 3; i++) jj += (fJ[fa][i * n + a] - fJ[fb][i * n + a]) * (fJ[fa][i * n + bb] - fJ[fb][i * n + bb]);
+                tl_C[row][a * n + bb] = (jj - Jg[row * nv + a] * Jg[row * nv + bb]) / dist;
+              }
+            if (with_fk_curv(d)) {
+              const double Fa[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist}, Fb[3] = {-Fa[0], -Fa[1], -Fa[2]};
+              orc_fk_curv(d, q, fa, Fa, tl_C[row]);
+              orc_fk_curv(d, q, fb, Fb, tl_C[row]);
+            }
+          }
+        } else if (d->xrow_kind[xr] == ORC_ROW_VAR) {
+          if (a0 < 0 || a0 >= nv) return -3;
+          g[row] = b0 > 0 ? z[a0] - p[po] : p[po] - z[a0];
+          if (want) Jg[row * nv + a0] = b0 > 0 ? 1.0 : -1.0;
+          if (a0 >= nx + ns) xrows_on_u = 1;
+        } else {
+          return -3;
+        }
+        row++;
+      }
     } else {
       return -3;
     }
-    const int x_only = (kind != ORC_MOD_INPUTLIMIT);
+    const int x_only = (kind == ORC_MOD_ROWS) ? !xrows_on_u : (kind != ORC_MOD_INPUTLIMIT);
     const int neutral = fixed_state && x_only && !ns;
     if (neutral) {
       for (int r = row0; r < row; r++) {
@@ -925,6 +1009,10 @@ static int model_uses_curvature(const orc_desc *d) {
     if (d->module_kind[mi] == ORC_MOD_SELFCOLLISION)
       for (int p = 0; p < d->n_pairs; p++)
         if (!frame_is_affine(d, d->pair_frame[p][0]) || !frame_is_affine(d, d->pair_frame[p][1])) return 0;
+  }
+  for (int r = 0; r < d->n_xrows; r++) {
+    if (d->xrow_kind[r] == ORC_ROW_RADIAL && !frame_is_affine(d, d->xrow_a[r])) return 0;
+    if (d->xrow_kind[r] == ORC_ROW_SELF && (!frame_is_affine(d, d->xrow_a[r]) || !frame_is_affine(d, d->xrow_b[r]))) return 0;
   }
   return 1;
 }

@@ -57,6 +57,13 @@ extern "C" {
 #define ORC_MOD_JOINTLIMIT 3
 #define ORC_MOD_VELLIMIT 4
 #define ORC_MOD_INPUTLIMIT 5
+/* a module given as row descriptions (include/rmpc.h RMPC_MOD_ROWS; rows in orc_desc::xrow_*) */
+#define ORC_MOD_ROWS 6
+#define ORC_MAX_XROWS 32
+#define ORC_ROW_RADIAL 0
+#define ORC_ROW_LINEAR 1
+#define ORC_ROW_SELF 2
+#define ORC_ROW_VAR 3
 
 /* joint types of the kinematic chain */
 #define ORC_JOINT_FIXED 0
@@ -97,6 +104,10 @@ typedef struct orc_desc {
   int32_t acc_iters;
   double acc_obj_tol;
   int32_t ls_max; /* halvings allowed in one line search (<= 0: ORC_LS_MAX) */
+  /* rows of the ORC_MOD_ROWS modules (include/rmpc.h: xrow_*): module index, row kind, a, b, parameter offset */
+  int32_t n_xrows;
+  int32_t xrow_mod[ORC_MAX_XROWS], xrow_kind[ORC_MAX_XROWS], xrow_a[ORC_MAX_XROWS], xrow_b[ORC_MAX_XROWS],
+      xrow_poff[ORC_MAX_XROWS];
 } orc_desc;
 
 /* Per-stage model evaluation (dense).  All matrices row-major.

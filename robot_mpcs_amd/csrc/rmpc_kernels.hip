@@ -5285,6 +5285,9 @@ static int build_model(const rmpc_desc &d, DevModel &M, std::string &err) {
   if (M.nv > RMPC_NV_MAX) { err = "nvar too large"; return -1; }
   M.n_modules = d.n_modules; M.nobst = d.nobst; M.end_frame = d.end_frame; M.n_joints = d.n_joints;
   if (d.n_modules < 0 || d.n_modules > RMPC_MAX_MODULES) { err = "n_modules out of range"; return -1; }
+  if (d.n_xrows < 0 || d.n_xrows > RMPC_MAX_XROWS) { err = "n_xrows out of range"; return -1; }
+  for (int r = 0; r < d.n_xrows; r++)
+    if (d.xrow_mod[r] < 0 || d.xrow_mod[r] >= d.n_modules || d.module_kind[d.xrow_mod[r]] != RMPC_MOD_ROWS) { err = "row description: xrow_mod must name a module of kind RMPC_MOD_ROWS"; return -1; }
   if (d.n_links < 0 || d.n_links > RMPC_MAX_LINKS || d.n_pairs < 0 || d.n_pairs > RMPC_MAX_PAIRS) { err = "links/pairs out of range"; return -1; }
   auto frame_ok = [&](int f) { return f >= 0 && f < d.n_joints; };
   if (!frame_ok(d.end_frame)) { err = "end_frame out of range"; return -1; }
@@ -5370,6 +5373,49 @@ static int build_model(const rmpc_desc &d, DevModel &M, std::string &err) {
           ok = ok && push(ROW_SINGLE, d.nx + d.ns + j, -1, d.off_upper_u + j, false);
         }
         break;
+      case RMPC_MOD_ROWS: {
+        // a module given as row descriptions (rmpc.h): variants of the six kinds through the same row tables
+        int on_x = 0, on_u = 0;
+        for (int r = 0; r < d.n_xrows && ok; r++) {
+          if (d.xrow_mod[r] != mi) continue;
+          const int a = d.xrow_a[r], b = d.xrow_b[r], po = d.xrow_poff[r];
+          switch (d.xrow_kind[r]) {
+            case RMPC_ROW_RADIAL:
+            case RMPC_ROW_LINEAR: {
+              const bool radial = d.xrow_kind[r] == RMPC_ROW_RADIAL;
+              int &base = radial ? M.off_obst : M.off_lin;
+              if (!frame_ok(a)) { err = "row description: frame"; return -1; }
+              if (!off_ok(d.off_r_body, 1) || !off_ok(po, 4)) { err = "row description: parameter offsets"; return -1; }
+              if (base < 0) base = po;   // (no module of the kind: the list starts at the first described row)
+              if (po < base || (po - base) % 4 != 0 || (po - base) / 4 > 63) {
+                err = "row description: a sphere / plane must lie a multiple of 4 (at most 252) parameters behind the obstacle / plane list";
+                return -1;
+              }
+              ok = push(radial ? ROW_RADIAL : ROW_LINEAR, a, (po - base) / 4, 0, true);
+              on_x++;
+              break;
+            }
+            case RMPC_ROW_SELF:
+              if (!frame_ok(a) || !frame_ok(b) || a == b) { err = "row description: pair frames"; return -1; }
+              if (!off_ok(d.off_r_body, 1)) { err = "row description: r_body"; return -1; }
+              ok = push(ROW_SELF, a, b, 0, true);
+              on_x++;
+              break;
+            case RMPC_ROW_VAR:
+              if (a < 0 || a >= M.nv || (d.ns && a == d.nx)) { err = "row description: variable"; return -1; }
+              if (b != 1 && b != -1) { err = "row description: sign must be +1 or -1"; return -1; }
+              if (!off_ok(po, 1)) { err = "row description: limit offset"; return -1; }
+              ok = push(ROW_SINGLE, a, b, po, false);
+              (a < d.nx ? on_x : on_u)++;
+              break;
+            default:
+              err = "row description: unknown row kind";
+              return -1;
+          }
+        }
+        if (on_x && on_u) { err = "row description: the rows of a module must all be on states or all on inputs"; return -1; }
+        break;
+      }
       default:
         err = "unknown constraint module";
         return -1;
@@ -5401,11 +5447,10 @@ static int build_model(const rmpc_desc &d, DevModel &M, std::string &err) {
   };
   bool curv = d.robot == RMPC_ROBOT_CHAIN && d.ns == 0;
   // (the arms carry the kinematics' own second derivatives: Cfg::FKCURV)
-  for (int mi = 0; mi < d.n_modules && curv && d.n <= 3; mi++) {
-    if (d.module_kind[mi] == RMPC_MOD_RADIAL)
-      for (int l = 0; l < d.n_links; l++) curv = curv && affine(d.link_frame[l]);
-    if (d.module_kind[mi] == RMPC_MOD_SELFCOLLISION)
-      for (int p = 0; p < d.n_pairs; p++) curv = curv && affine(d.pair_frame[p][0]) && affine(d.pair_frame[p][1]);
+  // (by row: the sphere and pair rows of the built-in modules and of the row-described ones alike)
+  for (int r = 0; r < M.nh && curv && d.n <= 3; r++) {
+    if (M.row_kind[r] == ROW_RADIAL) curv = curv && affine(M.row_a[r]);
+    if (M.row_kind[r] == ROW_SELF) curv = curv && affine(M.row_a[r]) && affine(M.row_b[r]);
   }
   if (d.robot == RMPC_ROBOT_DIFFDRIVE) curv = true;   // exact second-order terms of the unicycle (Cfg::DDCURV)
   M.use_curv = curv ? 1 : 0;
@@ -5919,9 +5964,21 @@ int rmpc_version(void) { return RMPC_VERSION; }
 #endif
 const char *rmpc_source_hash(void) { return RMPC_SOURCE_HASH; }
 const char *rmpc_last_error(void) { return g_err.c_str(); }
+/* a descriptor of this version, or of 0.2.0 (the struct without the xrow_* arrays at its end: no row-described modules) */
+static bool take_desc(const rmpc_desc *in, rmpc_desc &full) {
+  if (!in) return false;
+  const int old_size = (int)offsetof(rmpc_desc, n_xrows);
+  if (in->struct_size != (int)sizeof(rmpc_desc) && in->struct_size != old_size) return false;
+  memset(&full, 0, sizeof full);
+  memcpy(&full, in, (size_t)in->struct_size);
+  full.struct_size = (int)sizeof(rmpc_desc);
+  return true;
+}
 /* generated views: source text for one descriptor, and which view a handle runs (see rmpc.h) */
-int64_t rmpc_spec_source(const rmpc_desc *desc, const char *name, char *out, int64_t cap) {
-  if (!desc || !name || desc->struct_size != (int)sizeof(rmpc_desc)) return fail("rmpc_spec_source: bad arguments");
+int64_t rmpc_spec_source(const rmpc_desc *desc_in, const char *name, char *out, int64_t cap) {
+  rmpc_desc dfull;
+  if (!name || !take_desc(desc_in, dfull)) return fail("rmpc_spec_source: bad arguments");
+  const rmpc_desc *desc = &dfull;
   DevModel M;
   DevTables T;
   std::string err;
@@ -5931,8 +5988,10 @@ int64_t rmpc_spec_source(const rmpc_desc *desc, const char *name, char *out, int
   return (int64_t)src.size() + 1;
 }
 const char *rmpc_spec_name(rmpc_handle *h) { return h ? spec_name(h->spec) : ""; }
-const char *rmpc_spec_for(const rmpc_desc *desc) {
-  if (!desc || desc->struct_size != (int)sizeof(rmpc_desc)) return "";
+const char *rmpc_spec_for(const rmpc_desc *desc_in) {
+  rmpc_desc dfull;
+  if (!take_desc(desc_in, dfull)) return "";
+  const rmpc_desc *desc = &dfull;
   DevModel M;
   DevTables T;
   std::string err;
@@ -5942,8 +6001,10 @@ const char *rmpc_spec_for(const rmpc_desc *desc) {
 int rmpc_desc_size(void) { return (int)sizeof(rmpc_desc); }
 const char *rmpc_kernel_name(int idx) { return (idx >= 0 && idx < RMPC_NUM_KERNELS) ? kKernelNames[idx] : ""; }
 
-int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch) {
-  if (!desc || desc->struct_size != (int)sizeof(rmpc_desc) || max_batch < 1) return -1;
+int64_t rmpc_workspace_bytes(const rmpc_desc *desc_in, int max_batch) {
+  rmpc_desc dfull;
+  if (!take_desc(desc_in, dfull) || max_batch < 1) return -1;
+  const rmpc_desc *desc = &dfull;
   DevModel M;
   std::string err;
   if (build_model(*desc, M, err) != 0) { g_err = err; return -1; }
@@ -5957,9 +6018,11 @@ int64_t rmpc_workspace_bytes(const rmpc_desc *desc, int max_batch) {
   return (int64_t)(carve(M, Bp, passes_cap(M), nullptr, W) + (Bpc ? carve(M, Bpc, 0, nullptr, W) : 0) + fused);
 }
 
-int rmpc_create(const rmpc_desc *desc, int max_batch, rmpc_handle **out) {
-  if (!desc || !out) return fail("null argument");
-  if (desc->struct_size != (int)sizeof(rmpc_desc)) return fail("rmpc_desc size mismatch (ABI version?)");
+int rmpc_create(const rmpc_desc *desc_in, int max_batch, rmpc_handle **out) {
+  if (!desc_in || !out) return fail("null argument");
+  rmpc_desc dfull;
+  if (!take_desc(desc_in, dfull)) return fail("rmpc_desc size mismatch (ABI version?)");
+  const rmpc_desc *desc = &dfull;
   if (max_batch < 1) return fail("max_batch must be >= 1");
   rmpc_handle *h = new rmpc_handle();
   h->desc = *desc;

@@ -9,8 +9,13 @@ class InequalityManager:
         import robot_mpcs_amd.models.inequalities as registry
         self.names = list(ctx.config.constraints)
         self.modules = []
+        described = dict((ctx.plugins.get("constraints") or {}))
         for name in self.names:
-            module = getattr(registry, name)(ctx)     # unknown name: AttributeError, as in the reference
+            if not hasattr(registry, name) and name in described:
+                # a user-defined plug-in given as a row description (plugins: constraints: <name>: ...)
+                module = registry.DescribedRows(ctx, name, described[name])
+            else:
+                module = getattr(registry, name)(ctx)     # unknown name: AttributeError, as in the reference
             module.register(layout)
             self.modules.append(module)
 

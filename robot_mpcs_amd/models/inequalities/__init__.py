@@ -5,4 +5,5 @@ from robot_mpcs_amd.models.inequalities._modules import (
     InputLimitConstraints,
     RadialConstraints,
     LinearConstraints,
+    DescribedRows,
 )

@@ -66,6 +66,101 @@ def _make(name):
     return type(name, (InequalityModule,), {"NAME": name, "__doc__": "constraint plug-in '%s' (see SPECS)" % name})
 
 
+class DescribedRows:
+    """A constraint plug-in given as a ROW DESCRIPTION in the YAML (top-level block ``plugins: constraints: <name>:``)
+    instead of a class: the counterpart of dropping a user class into ``robotmpcs/models/inequalities`` and naming it
+    in ``mpc.constraints`` (``InequalityManager.py:17-21``).  The vocabulary is what the kernels evaluate
+    (include/rmpc.h ``RMPC_ROW_*``) -- variants of the six modules on other links, pairs, joints or inputs, with
+    parameter entries of their own -- lowered through the runtime row tables: no rebuild of the library.
+
+      rows: radial    links: [...]            spheres: k     entry ``<name>`` (4 k: x y z r per sphere)
+      rows: linear    links: [...]            planes: k      entry ``<name>`` (4 k: a b c d per plane)
+      rows: self      pairs: [[a, b], ...]
+      rows: limits    variables: q | qdot | u indices: [...] entries ``<name>_lower`` / ``<name>_upper``
+                      (the key is not called ``on``: YAML 1.1 reads that as a boolean)
+    ``params: <entry>`` instead of ``spheres`` / ``planes`` re-uses an entry registered earlier (e.g. ``obst``).
+    Row order as in the built-in modules: links outer, objects inner; lower then upper per index."""
+    KIND = 6    # RMPC_MOD_ROWS
+    ROW_RADIAL, ROW_LINEAR, ROW_SELF, ROW_VAR = 0, 1, 2, 3
+
+    def __init__(self, ctx: ModelContext, name: str, spec: dict):
+        self.NAME, self._ctx, self._spec = name, ctx, dict(spec)
+        kind = self._spec.get("rows")
+        if kind in ("radial", "linear"):
+            self._links = [ctx.chain.frame_of(l) for l in self._spec["links"]]
+            self._count = int(self._spec.get("spheres", self._spec.get("planes", 0)))
+            self._shared = self._spec.get("params")
+            if not self._shared and self._count < 1:
+                raise ValueError("plug-in '%s': give spheres / planes (a count) or params (an existing entry)" % name)
+            self._n_ineq = None if self._shared else len(self._links) * self._count
+        elif kind == "self":
+            self._pairs = [[ctx.chain.frame_of(a), ctx.chain.frame_of(b)] for a, b in self._spec["pairs"]]
+            self._n_ineq = len(self._pairs)
+        elif kind == "limits":
+            if "variables" not in self._spec:
+                raise ValueError("plug-in '%s': variables must be q, qdot or u" % name)
+            on = self._spec["variables"]
+            base = {"q": 0, "qdot": ctx.n, "u": ctx.nx + ctx.ns}.get(on)
+            if base is None:
+                raise ValueError("plug-in '%s': variables must be q, qdot or u" % name)
+            top = {"q": ctx.n, "qdot": ctx.nx - ctx.n, "u": ctx.nu}[on]
+            self._vars = []
+            for i in self._spec["indices"]:
+                if not 0 <= int(i) < top:
+                    raise ValueError("plug-in '%s': index %s out of range" % (name, i))
+                self._vars.append(base + int(i))
+            self._n_ineq = 2 * len(self._vars)
+        else:
+            raise ValueError("plug-in '%s': rows must be radial, linear, self or limits" % name)
+        self._kind = kind
+
+    def register(self, layout: ParamLayout) -> None:
+        name = self.NAME
+        if self._kind in ("radial", "linear"):
+            layout.add("r_body", 1)
+            if self._shared:
+                if self._shared not in layout.entries or len(layout.entries[self._shared]) % 4:
+                    raise ValueError("plug-in '%s': params '%s' is no registered entry of 4 k values" % (name, self._shared))
+                self._count = len(layout.entries[self._shared]) // 4
+                self._n_ineq = len(self._links) * self._count
+                self._entry = self._shared
+            else:
+                # (the kernels address a sphere / plane as an entry of the obstacle / plane list: 4-aligned behind it)
+                anchor = layout.offset("obst" if self._kind == "radial" else "lin_constrs_0")
+                if anchor < 0:
+                    anchor = getattr(layout, "_anchor_" + self._kind, -1)
+                if anchor < 0:
+                    anchor = layout.size
+                    setattr(layout, "_anchor_" + self._kind, anchor)
+                layout.pad_to(anchor, 4)
+                layout.add(name, 4 * self._count)
+                self._entry = name
+        elif self._kind == "self":
+            layout.add("r_body", 1)
+        else:
+            layout.add(name + "_lower", len(self._vars))
+            layout.add(name + "_upper", len(self._vars))
+
+    def rows(self, layout: ParamLayout, module_index: int):
+        """(module, kind, a, b, parameter offset) per row, in row order: rmpc_desc::xrow_*"""
+        out = []
+        if self._kind in ("radial", "linear"):
+            off = layout.offset(self._entry)
+            rk = self.ROW_RADIAL if self._kind == "radial" else self.ROW_LINEAR
+            for f in self._links:
+                for i in range(self._count):
+                    out.append((module_index, rk, f, 0, off + 4 * i))
+        elif self._kind == "self":
+            for a, b in self._pairs:
+                out.append((module_index, self.ROW_SELF, a, b, 0))
+        else:
+            lo, hi = layout.offset(self.NAME + "_lower"), layout.offset(self.NAME + "_upper")
+            for i, v in enumerate(self._vars):
+                out.append((module_index, self.ROW_VAR, v, +1, lo + i))
+                out.append((module_index, self.ROW_VAR, v, -1, hi + i))
+        return out
+
+
 RadialConstraints = _make("RadialConstraints")
 LinearConstraints = _make("LinearConstraints")
 SelfCollisionAvoidanceConstraints = _make("SelfCollisionAvoidanceConstraints")

@@ -70,6 +70,12 @@ class ParamLayout:
     def offset(self, name: str) -> int:
         return self.entries[name][0] if name in self.entries else -1
 
+    def pad_to(self, anchor: int, multiple: int) -> None:
+        """Padding entries until ``size - anchor`` is a multiple of ``multiple`` (described sphere / plane rows address
+        their parameters as entries of the obstacle / plane list: include/rmpc.h, ``xrow_poff``)."""
+        while (self.size - anchor) % multiple:
+            self.add("_pad%d" % self.size, 1)
+
 
 class ModelContext:
     """What every plug-in needs to know about the model: config, chain, dimensions."""
@@ -79,6 +85,9 @@ class ModelContext:
         self.config = MpcConfiguration(**setup['mpc'])
         self.debug = setup['example']['debug']
         self.robot = RobotConfiguration(**setup['robot'])
+        # row descriptions of user-defined plug-ins: a top-level YAML block of this project (the reference reads the
+        # keys it knows from the top-level dict and ignores the rest; its 'mpc' / 'robot' schemas stay untouched)
+        self.plugins = dict(setup.get('plugins') or {})
         self.chain = _chain_of(self.robot.urdf_file, self.robot.root_link, self.robot.end_link)
         dof = self.chain.n()
         if self.robot.base_type == 'holonomic':          # mpcBase.py:52-55

@@ -164,6 +164,13 @@ class MpcModel:
             "erk_nodes": 5,
             "options": dict(self._options),
         }
+        # rows of the plug-ins given as row descriptions (include/rmpc.h RMPC_MOD_ROWS)
+        xrows = []
+        for mi, m in enumerate(modules):
+            if hasattr(m, "rows"):
+                xrows += [[int(v) for v in r] for r in m.rows(self._layout, mi)]
+        if xrows:
+            self._model["xrows"] = xrows
         return self._model
 
     def setCodeoptions(self, **kwargs):

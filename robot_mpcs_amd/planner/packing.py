@@ -60,6 +60,12 @@ class ParamPacker:
         if self._config.slack:
             p3[:, :, self.idx("ws")] = self._config.weights["ws"]
 
+    def setEntry(self, name, value):
+        """Parameter entry ``name`` of every stage: ``value`` broadcast to (B, N, len(entry)) -- the setter of the
+        plug-ins given as row descriptions (their entries: ``<name>``, ``<name>_lower`` / ``<name>_upper``)."""
+        ix = self.idx(name)
+        self.p3[:, :, ix] = self._bcast(value, (self.B, self.N, len(ix)))
+
     # -- setters (reference mpcPlanner.py:120-210) -----------------------
     def setRadialConstraints(self, obst_pos, obst_radius, r_body):
         """obst_pos (..., n_given, 3), obst_radius (..., n_given); slots beyond

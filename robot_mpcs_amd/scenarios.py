@@ -45,6 +45,9 @@ CONFIG_FILES = {
     "chain4": "t_chain4Mpc.yaml",
     "chain6": "t_chain6Mpc.yaml",
     "chain8": "t_chain8Mpc.yaml",
+    # constraint plug-ins given as row descriptions (top-level YAML block `plugins`, include/rmpc.h RMPC_MOD_ROWS)
+    "plug_point": "plug_pointRobotMpc.yaml",
+    "plug_panda": "plug_pandaMpc.yaml",
 }
 DEFAULT_BATCH = {"cfg1": 1, "cfg2": 4096, "cfg3": 4096, "cfg4": 1024}
 
@@ -159,9 +162,16 @@ def make_scenario(name: str, B: int | None = None, seed: int = 0, **mpc_override
             opos[idx, :, :2] = c[ok]; orad[idx] = r[ok]
             todo[idx] = False
         xinit[:, 0:2] = start
-        pk.setRadialConstraints(opos, orad, r_body)
-        pk.setJointLimits(POINT_LIMITS[:, :model._n])
-        pk.setInputLimits(POINT_LIMITS_U[:, :model._n])
+        if name == "plug_point":
+            # the same numbers through the parameter entries of the described plug-ins (cfg2's rows, see the YAML)
+            pk.setEntry("r_body", r_body)
+            pk.setEntry("KeepOutSpheres", np.concatenate([opos, orad[:, :, None]], axis=2).reshape(B, 1, 4 * nob))
+            pk.setEntry("AxisLimits_lower", POINT_LIMITS[0]); pk.setEntry("AxisLimits_upper", POINT_LIMITS[1])
+            pk.setEntry("ThrustLimits_lower", POINT_LIMITS_U[0]); pk.setEntry("ThrustLimits_upper", POINT_LIMITS_U[1])
+        else:
+            pk.setRadialConstraints(opos, orad, r_body)
+            pk.setJointLimits(POINT_LIMITS[:, :model._n])
+            pk.setInputLimits(POINT_LIMITS_U[:, :model._n])
         g3 = np.concatenate([goal, np.zeros((B, 1))], axis=1)
         pk.setGoalReaching(g3)
         extra.update(goal=g3, r_body=r_body, obst_pos=opos, obst_radius=orad)
@@ -242,6 +252,13 @@ def make_scenario(name: str, B: int | None = None, seed: int = 0, **mpc_override
         pk.setInputLimits(limu)
         pk.setGoalReaching(goal)
         extra.update(goal=goal, r_body=r_body, obst_pos=opos)
+        if name == "plug_panda":
+            # a keep-out sphere above the base for links 5 and 7 (clear of the start poses), speed limits of the wrist
+            keep = np.array([-0.35, 0.25, 0.75]) + jit(0.05, (B, 3))
+            pk.setEntry("KeepOut", np.concatenate([keep, np.full((B, 1), 0.08)], axis=1)[:, None, :])
+            pk.setEntry("WristSpeed_lower", np.array([-0.05, -0.05]))
+            pk.setEntry("WristSpeed_upper", np.array([0.05, 0.05]))
+            extra.update(keep_out=keep)
     else:
         raise KeyError(robot)
     if "ConstraintAvoidance" in setup["mpc"]["objectives"]:

@@ -34,7 +34,7 @@ def test_descriptor_layout_and_version(lib):
     # the macro of include/rmpc.h is what the library reports (0.2.0: rmpc_retarget struct, rmpc_advance_obstacles_device)
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rmpc.h")).read()
     ver = int(re.search(r"#define RMPC_VERSION (\d+)", hdr).group(1))
-    assert L.rmpc_version() == ver == 200
+    assert L.rmpc_version() == ver == 201
     assert [L.rmpc_kernel_name(i).decode() for i in range(5)] == ["k_pack", "k_sweep", "k_riccati", "k_step", "k_unpack"]
 
 
