@@ -228,6 +228,11 @@ class MPCPlanner(_PlannerCore):
     def setConstraintAvoidance(self):
         self._packer.setConstraintAvoidance()
 
+    def setEntry(self, name, value):
+        """Parameter entry of a constraint plug-in given as a row description (YAML block ``plugins``; entries
+        ``<name>``, ``<name>_lower`` / ``<name>_upper``): ``value`` is broadcast over the stages."""
+        self._packer.setEntry(name, np.asarray(value, dtype=float))
+
     def concretize(self):
         self._actionCounter = self._config.interval
 

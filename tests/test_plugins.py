@@ -33,6 +33,19 @@ def test_described_rows_reach_the_descriptor():
         make_scenario("cfg2", B=1, constraints=["RadialConstraints", "NoSuchConstraints"])
 
 
+def test_described_rows_survive_the_solver_directory(tmp_path):
+    """generateSolver writes the rows into rmpc_model.yaml; the planner reads them back (mpcPlanner.py:73 counterpart)."""
+    import os
+    from robot_mpcs_amd.models.mpcModel import DESCRIPTOR_FILE, load_descriptor
+    sc = make_scenario("plug_panda", B=1, seed=1)
+    target = sc.model.generateSolver(location=str(tmp_path) + "/")
+    back = load_descriptor(os.path.join(target, DESCRIPTOR_FILE))
+    assert back["xrows"] == sc.desc["xrows"] and back["module_kind"] == [0, 6, 3, 5, 6, 6]
+    import yaml
+    pm = yaml.safe_load(open(os.path.join(target, "paramMap.yaml")))
+    assert len(pm["KeepOut"]) == 4 and len(pm["WristSpeed_lower"]) == 2
+
+
 def test_described_twin_of_cfg2_is_cfg2_for_the_oracle():
     """plug_pointRobotMpc.yaml describes cfg2's sphere, joint-limit and input-limit rows one by one: same rows, same order,
     same numbers through other parameter entries -- the restatement returns bit-identical plans."""
