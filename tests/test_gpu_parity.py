@@ -150,6 +150,22 @@ def test_arm_horizons_around_the_lds_image_slots(rt, N):
     np.testing.assert_allclose(gpu["obj"], cpu["obj"], rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("name", ["cfg2", "chain2"])
+@pytest.mark.parametrize("N", [1, 2, 5, 31, 32])
+def test_fused_point_robot_horizons_match_oracle(rt, name, N):
+    """The block-form recursion of k_fused (chains with n <= 3 joints and no slack: the cost-to-go stays in the registers
+    of the lanes of an n x n grid from stage to stage, two ordering points per backward stage) at the edges of its stage
+    loop: a single stage (no recursion to speak of), two stages, and the last horizons the 32 slots of an instance hold."""
+    sc = rt["make_scenario"](name, B=48, seed=100 + N, time_horizon=N)
+    cpu = rt["Oracle"](sc.desc).solve_batch(sc.xinit, sc.x0, sc.params)
+    s = rt["Solver"](sc.desc, max_batch=48)
+    assert s.is_fused()
+    gpu = s.solve(sc.xinit, sc.x0, sc.params)
+    s.close()
+    _check_plan(gpu, cpu, sc.desc["nx"] + sc.desc["ns"])
+    np.testing.assert_allclose(gpu["obj"], cpu["obj"], rtol=1e-9, atol=1e-9)
+
+
 @pytest.mark.parametrize("name,B,kw", [
     ("cfg1", 3, {}), ("cfg2", 2048, {}), ("cfg3", 512, {}),
     # the pass kernels: the arm (its sweep keeps the q blocks, the next stage's state and the costates in LDS columns,
