@@ -521,7 +521,10 @@ def main():
         # the other robots of the metric, same box, same run (shorter legs)
         for other in ("cfg4", "cfg3"):
             lo = Leg(other, DEFAULT_BATCH[other], S, 4, dev, 2000 + 101 * rank)
-            k = max(16, args.steps // 4)
+            # (at least 48 steps = 12 launches per stream: a stream's last launch ends with its slowest instances alone
+            #  on the chip, and with four launches per stream that tail was a quarter of the leg -- cfg4 0.78 M over 16
+            #  steps, 0.83-0.85 M over 50; the two legs together still take under half a second)
+            k = max(48, args.steps // 4)
             el = fleet.max_over_ranks(timed(lo, k, 4, fence), dd, cdev)
             ef, it, kk = lo.stats()
             st = fleet.summarize(fleet.gather_stats(fleet.solve_stats(ef, it, kk), dd, cdev), lo.B)
