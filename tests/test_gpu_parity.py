@@ -150,6 +150,21 @@ def test_arm_horizons_around_the_lds_image_slots(rt, N):
     np.testing.assert_allclose(gpu["obj"], cpu["obj"], rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("B,seed,kw", [(160, 91, {}), (48, 92, {"time_horizon": 7}), (48, 93, {"time_horizon": 32})])
+def test_fused_point_robot_with_slack_matches_oracle(rt, B, seed, kw):
+    """The point robot with the slack variable (`slack: true`: Cfg<CHAIN, 3, 1>) is the one model that still runs the
+    gain-form in-LDS recursion of k_fused (`FAST` in riccati_recursion) since the chains without slack moved to the block
+    form: kept under test on its own -- flags, iteration counts and plans against the oracle."""
+    sc = rt["make_scenario"]("cfg2", B=B, seed=seed, slack=True, **kw)
+    assert sc.desc["ns"] == 1
+    cpu = rt["Oracle"](sc.desc).solve_batch(sc.xinit, sc.x0, sc.params)
+    s = rt["Solver"](sc.desc, max_batch=B)
+    assert s.is_fused()
+    gpu = s.solve(sc.xinit, sc.x0, sc.params)
+    s.close()
+    _check_plan(gpu, cpu, sc.desc["nx"] + sc.desc["ns"])
+
+
 @pytest.mark.parametrize("name", ["cfg2", "chain2"])
 @pytest.mark.parametrize("N", [1, 2, 5, 31, 32])
 def test_fused_point_robot_horizons_match_oracle(rt, name, N):
