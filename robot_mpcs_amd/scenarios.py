@@ -48,6 +48,7 @@ CONFIG_FILES = {
     # constraint plug-ins given as row descriptions (top-level YAML block `plugins`, include/rmpc.h RMPC_MOD_ROWS)
     "plug_point": "plug_pointRobotMpc.yaml",
     "plug_panda": "plug_pandaMpc.yaml",
+    "plug_boxer": "plug_boxerMpc.yaml",
 }
 DEFAULT_BATCH = {"cfg1": 1, "cfg2": 4096, "cfg3": 4096, "cfg4": 1024}
 
@@ -207,7 +208,7 @@ def make_scenario(name: str, B: int | None = None, seed: int = 0, **mpc_override
         if "LinearConstraints" in constraints and nob == 1:
             lin = np.tile(np.array([1.0, 0.0, 0.0, -100.0]), (pk.N, nob, 1))
             pk.setLinearConstraints(lin, r_body)
-        elif "LinearConstraints" in constraints:
+        elif "LinearConstraints" in constraints or name == "plug_boxer":
             # planes at 2.0 .. 3.5 from the lidar point of the start pose, random normals, the robot on the free side
             ee = xinit[:, 0:2] + 0.4 * np.stack([np.cos(xinit[:, 2]), np.sin(xinit[:, 2])], 1)
             phi = rng.uniform(-np.pi, np.pi, size=(B, nob))
@@ -215,7 +216,13 @@ def make_scenario(name: str, B: int | None = None, seed: int = 0, **mpc_override
             dist = rng.uniform(2.0, 3.5, size=(B, nob))
             dcoef = dist * np.linalg.norm(nrm, axis=2) - np.einsum("bij,bj->bi", nrm[:, :, :2], ee)
             lin = np.concatenate([nrm, dcoef[:, :, None]], axis=2)            # a.p + d = dist * |a| at the start
-            pk.setLinearConstraints(np.broadcast_to(lin[:, None], (B, pk.N, nob, 4)), r_body)
+            if name == "plug_boxer":
+                # (wc_boxer's numbers through the entries of the described plug-ins, see the YAML)
+                pk.setEntry("r_body", r_body)
+                pk.setEntry("Walls", lin.reshape(B, 1, 4 * nob))
+                pk.setEntry("SpeedLimits_lower", BOXER_LIMITS_VEL[0]); pk.setEntry("SpeedLimits_upper", BOXER_LIMITS_VEL[1])
+            else:
+                pk.setLinearConstraints(np.broadcast_to(lin[:, None], (B, pk.N, nob, 4)), r_body)
             extra.update(lin_constrs=lin)
     elif robot == "panda":
         r_body = 0.14

@@ -46,10 +46,12 @@ def test_described_rows_survive_the_solver_directory(tmp_path):
     assert len(pm["KeepOut"]) == 4 and len(pm["WristSpeed_lower"]) == 2
 
 
-def test_described_twin_of_cfg2_is_cfg2_for_the_oracle():
-    """plug_pointRobotMpc.yaml describes cfg2's sphere, joint-limit and input-limit rows one by one: same rows, same order,
+@pytest.mark.parametrize("builtin,twin", [("cfg2", "plug_point"), ("wc_boxer", "plug_boxer")])
+def test_described_twin_is_the_builtin_configuration_for_the_oracle(builtin, twin):
+    """plug_pointRobotMpc.yaml describes cfg2's sphere, joint-limit and input-limit rows one by one, plug_boxerMpc.yaml the
+    planes and the speed limits of wc_boxer (a diff-drive base; limits on the last two states): same rows, same order,
     same numbers through other parameter entries -- the restatement returns bit-identical plans."""
-    a, b = make_scenario("cfg2", B=24, seed=5), make_scenario("plug_point", B=24, seed=5)
+    a, b = make_scenario(builtin, B=24, seed=5), make_scenario(twin, B=24, seed=5)
     ra, rb = _oracle(a), _oracle(b)
     assert np.array_equal(ra["exitflag"], rb["exitflag"]) and np.array_equal(ra["iters"], rb["iters"])
     assert np.array_equal(ra["z"], rb["z"])
@@ -106,7 +108,7 @@ def test_library_validates_row_descriptions():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,B,seed,fused", [("plug_point", 160, 11, True), ("plug_panda", 48, 12, False)])
+@pytest.mark.parametrize("name,B,seed,fused", [("plug_point", 160, 11, True), ("plug_panda", 48, 12, False), ("plug_boxer", 96, 13, True)])
 def test_described_rows_on_the_gpu_match_the_oracle(name, B, seed, fused):
     """HIP library vs restatement on the described plug-ins: flags, iteration counts, plans.  The point robot stays in
     k_fused; the arm's wrist speed limits break the uniform row structure k_fused_arm relies on, so it runs the pass kernels."""
@@ -124,6 +126,17 @@ def test_described_rows_on_the_gpu_match_the_oracle(name, B, seed, fused):
     nxs = sc.desc["nx"] + sc.desc["ns"]
     du = np.abs(gpu["z"][ok][:, 0, nxs:] - cpu["z"][ok][:, 0, nxs:]).max()
     assert du <= 1e-6 * max(1.0, np.abs(cpu["z"][ok][:, 0, nxs:]).max()), du
+
+
+@pytest.mark.gpu
+def test_described_twin_of_wc_boxer_is_wc_boxer_on_the_gpu():
+    """Both run k_fused over the runtime tables, and the tables come out equal entry for entry: bit-identical plans."""
+    from robot_mpcs_amd._lib import Solver
+    a, b = make_scenario("wc_boxer", B=128, seed=22), make_scenario("plug_boxer", B=128, seed=22)
+    sa = Solver(a.desc, max_batch=128); ra = sa.solve(a.xinit, a.x0, a.params); sa.close()
+    sb = Solver(b.desc, max_batch=128); rb = sb.solve(b.xinit, b.x0, b.params); sb.close()
+    assert np.array_equal(ra["exitflag"], rb["exitflag"]) and np.array_equal(ra["iters"], rb["iters"])
+    assert np.array_equal(ra["z"], rb["z"])
 
 
 @pytest.mark.gpu
