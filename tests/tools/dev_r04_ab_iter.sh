@@ -1,3 +1,4 @@
+# development aid (round 4): iterates after 1 .. 16 iterations with two development libraries (dev / dev2) compared: the first iteration at which a changed recursion gives another step
 export RMPC_ALLOW_STALE=1
 mkdir -p gpurun_out
 for l in dev dev2; do RMPC_LIB_PATH=$PWD/robot_mpcs_amd/csrc/librmpc_hip_$l.so timeout -k 10 200 python tests/tools/dev_ab_iter.py gpurun_out/abit_$l.npz ${1:-cfg3} ${2:-4} 2>&1 | grep -v amdgpu; done

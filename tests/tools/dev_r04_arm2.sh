@@ -1,3 +1,4 @@
+# development aid (round 4): runtime-table fused models of the development library against the oracle, then cfg3 timing
 mkdir -p gpurun_out
 for c in "cfg3 256 1000" "wc_boxer_slack 96 33" "chain2 96 41" "wc_point 96 31"; do
   echo "== $c"

@@ -1,3 +1,4 @@
+# development aid (round 4): phase stamps of k_fused_arm at 128 .. 1024 wavefronts (where the loaded pass loses against the lone one)
 set -e
 mkdir -p gpurun_out
 export RMPC_ALLOW_STALE=1 RMPC_LIB_PATH=$PWD/robot_mpcs_amd/csrc/librmpc_hip_dev.so

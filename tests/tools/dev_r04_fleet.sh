@@ -1,3 +1,4 @@
+# development aid (round 4): the mixed-fleet tests with the development settings
 mkdir -p gpurun_out
 timeout -k 10 600 python bench.py --config cfg5 --steps 400 --warmup 10 > gpurun_out/r04_cfg5.json 2> gpurun_out/r04_cfg5.err || { tail gpurun_out/r04_cfg5.err; exit 1; }
 python - <<'PY'

@@ -1,3 +1,4 @@
+# development aid (round 4): phase stamps of k_fused for one configuration (library built with -DRMPC_STAMPS)
 set -e
 mkdir -p gpurun_out
 export RMPC_ALLOW_STALE=1

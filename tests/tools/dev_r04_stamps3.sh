@@ -1,3 +1,4 @@
+# development aid (round 4): phase stamps of the boxer's k_fused (library: scripts/dev_build.sh 0x20 -DRMPC_STAMPS)
 set -e
 mkdir -p gpurun_out
 export RMPC_ALLOW_STALE=1

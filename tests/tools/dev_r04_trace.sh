@@ -1,3 +1,4 @@
+# development aid (round 4): rocprofv3 kernel trace of several handles in flight, summarised with tests/tools/trace_load.py
 export TMPDIR=/tmp
 R=$PWD
 mkdir -p gpurun_out
