@@ -128,10 +128,7 @@ class DescribedRows:
                 # (the kernels address a sphere / plane as an entry of the obstacle / plane list: 4-aligned behind it)
                 anchor = layout.offset("obst" if self._kind == "radial" else "lin_constrs_0")
                 if anchor < 0:
-                    anchor = getattr(layout, "_anchor_" + self._kind, -1)
-                if anchor < 0:
-                    anchor = layout.size
-                    setattr(layout, "_anchor_" + self._kind, anchor)
+                    anchor = layout.anchors.setdefault(self._kind, layout.size)
                 layout.pad_to(anchor, 4)
                 layout.add(name, 4 * self._count)
                 self._entry = name

@@ -60,6 +60,9 @@ class ParamLayout:
     def __init__(self):
         self.entries: Dict[str, List[int]] = {}
         self.size = 0
+        # where the sphere / plane list of the described plug-ins starts when no built-in module registered one
+        # (inequalities/_modules.py DescribedRows: their entries are 4-aligned behind it)
+        self.anchors: Dict[str, int] = {}
 
     def add(self, name: str, count: int) -> None:
         if name in self.entries:       # first registration wins (mpcBase.py:68-71)
