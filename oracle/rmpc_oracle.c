@@ -675,6 +675,14 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
 #define ORC_LS_CURV 2       /* trials granted to a step computed with constraint curvature */
 #define ORC_CURV_FAIL_MAX 2 /* consecutive curvature-step failures before latching Gauss-Newton */
 #define ORC_ACC_FEAS 1e-6   /* ... feasibility / complementarity level */
+/* barrier restart (round 4): from iteration ORC_RS_IT on, ORC_RS_N accepted steps in a row shorter than ORC_RS_ALPHA
+ * while mu < ORC_RS_MU mean the iterate crawls along a boundary with the barrier at its floor: mu is held at ORC_RS_MU
+ * and released by the factor ORC_RS_DECAY per iteration */
+#define ORC_RS_IT 8
+#define ORC_RS_N 3
+#define ORC_RS_ALPHA 0.2
+#define ORC_RS_MU 1e-3
+#define ORC_RS_DECAY 0.3
 #define ORC_TRACE_W 8
 
 typedef struct {
@@ -1061,6 +1069,8 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
   memcpy(w->z, xinit, sizeof(double) * nx); /* x_1 = xinit (mpcModel.py:108 xinitidx) */
   memset(st, 0, sizeof *st);
   double mu = d->mu0, rho = 0.0;
+  int small_steps = 0;   /* barrier restart: accepted short steps in a row, the level mu is held at */
+  double mu_hold = 0.0;
   int exitflag = 0, it = 0;
   const int curv_ok = model_uses_curvature(d);
   int gn_sticky = 0, curv_fail = 0, stall = 0;
@@ -1288,6 +1298,16 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
       if (sg > 0.8) sg = 0.8;
       mu = sg * avg;
       if (mu < 0.1 * d->tol_comp) mu = 0.1 * d->tol_comp;
+    }
+    /* ---- barrier restart on stalled steps ---- */
+    {
+      small_steps = (it >= ORC_RS_IT && alpha < ORC_RS_ALPHA) ? small_steps + 1 : 0;
+      if (small_steps >= ORC_RS_N && mu < ORC_RS_MU && !(mu_hold > 0.0)) { mu_hold = ORC_RS_MU; small_steps = 0; }
+      if (mu_hold > 0.0) {
+        if (mu < mu_hold) mu = mu_hold;
+        mu_hold *= ORC_RS_DECAY;
+        if (mu_hold < 0.1 * d->tol_comp) mu_hold = 0.0;
+      }
     }
     if (!(mu < ORC_MU_DIVERGED)) { exitflag = -7; it++; break; } /* infeasible / diverged */
     ev = eval_all(d, w, params);

@@ -77,6 +77,9 @@ constexpr double kWarmKappa = 1000.0;
 constexpr double kWarmMuMin = 1e-6;
 constexpr double kWarmTMin = 1e-4;
 constexpr double kTau = 0.995;
+// barrier restart on stalled steps (oracle: ORC_RS_IT, ORC_RS_N, ORC_RS_ALPHA, ORC_RS_MU, ORC_RS_DECAY)
+constexpr int kRsIt = 8, kRsN = 3;
+constexpr double kRsAlpha = 0.2, kRsMu = 1e-3, kRsDecay = 0.3;
 constexpr int kSweepBlock = 64;     // threads per k_sweep / k_step block: one wavefront, so that small batches spread over all CUs
 constexpr int kLsMax = 25;
 constexpr int kLsGrow = 1;         // step-length memory: a line search starts this many halvings above the last accepted one
@@ -120,10 +123,12 @@ struct Ws {
   unsigned long long *amin_p, *amin_d;  // [Bp] fraction-to-the-boundary step lengths (bits of a positive double)
   // per instance [Bp]
   double *mu, *rho, *phi0, *Dd, *fcur, *thcur, *logcur;
+  double *mu_hold;                // barrier restart (inst_decide): the level mu is held at, 0 = none
   double *res_stat, *res_eq, *res_ineq, *res_comp, *obj;
   int *status, *iters, *ls, *cur, *newstep;
   int *redo, *force_gn, *gn_sticky, *curv_fail, *usedc, *stall;
   int *curv_skip, *curv_back;     // (diff-drive) curvature steps still to be skipped / length of the last skip (back-off)
+  int *small_steps;               // barrier restart: accepted short steps in a row
   int *ls0, *lsst;                // halvings the current line search started from / the next one starts from
   int *active_hist;               // [max_passes] instances still iterating after each pass
   int *act_idx, *n_act;           // compacted list of the instances still iterating, its length
@@ -195,6 +200,7 @@ __global__ __launch_bounds__(256) void k_init(Ws W, const double *__restrict__ x
   W.amin_d[b] = (unsigned long long)__double_as_longlong(1.0);
   W.redo[b] = 0; W.force_gn[b] = 0; W.gn_sticky[b] = 0; W.curv_fail[b] = 0; W.usedc[b] = 0; W.stall[b] = 0;
   W.curv_skip[b] = 0; W.curv_back[b] = 0;
+  W.small_steps[b] = 0; W.mu_hold[b] = 0.0;
   W.ls0[b] = 0; W.lsst[b] = 0;
   W.mu[b] = warm ? warm_mu(W.wmu[b], mu0) : mu0;
   W.rho[b] = 0.0;
@@ -416,6 +422,7 @@ __global__ __launch_bounds__(64) void k_migrate(const Ws S, const Ws D, int n, i
     D.redo[li] = S.redo[b]; D.force_gn[li] = S.force_gn[b]; D.gn_sticky[li] = S.gn_sticky[b];
     D.curv_fail[li] = S.curv_fail[b]; D.usedc[li] = S.usedc[b]; D.stall[li] = S.stall[b];
     D.curv_skip[li] = S.curv_skip[b]; D.curv_back[li] = S.curv_back[b];
+    D.small_steps[li] = S.small_steps[b]; D.mu_hold[li] = S.mu_hold[b];
     D.ls0[li] = S.ls0[b]; D.lsst[li] = S.lsst[b];
     D.cur[li] = 0;
     D.orig[li] = b;
@@ -1438,7 +1445,9 @@ __device__ __forceinline__ void wave_reduce_many(double (&sums)[NS_], double (&m
 struct Inst {
   double mu, rho, phi0, Dd, fcur, thcur, logcur, res_stat, res_eq, res_ineq, res_comp, obj;
   double amin_p, amin_d;   // fraction-to-the-boundary step lengths of the current step
+  double mu_hold;          // barrier restart: the level mu is held at (0: none)
   int status, iters, ls, ls0, lsst, cur, newstep, redo, force_gn, gn_sticky, curv_fail, usedc, stall, curv_skip, curv_back;
+  int small_steps;         // barrier restart: accepted short steps in a row
 };
 __device__ __forceinline__ void inst_init(Inst &s, double mu0) {
   s.mu = mu0; s.rho = 0.0; s.phi0 = 0.0; s.Dd = 0.0; s.fcur = 0.0; s.thcur = 0.0; s.logcur = 0.0;
@@ -1446,6 +1455,7 @@ __device__ __forceinline__ void inst_init(Inst &s, double mu0) {
   s.amin_p = 1.0; s.amin_d = 1.0;
   s.status = ST_ACTIVE; s.iters = 0; s.ls = 0; s.ls0 = 0; s.lsst = 0; s.cur = 0; s.newstep = 0; s.redo = 0;
   s.force_gn = 0; s.gn_sticky = 0; s.curv_fail = 0; s.usedc = 0; s.stall = 0; s.curv_skip = 0; s.curv_back = 0;
+  s.small_steps = 0; s.mu_hold = 0.0;
 }
 __device__ __forceinline__ void inst_load(Inst &s, const Ws &W, int b) {
   s.mu = W.mu[b]; s.rho = W.rho[b]; s.phi0 = W.phi0[b]; s.Dd = W.Dd[b]; s.fcur = W.fcur[b]; s.thcur = W.thcur[b];
@@ -1455,6 +1465,7 @@ __device__ __forceinline__ void inst_load(Inst &s, const Ws &W, int b) {
   s.status = W.status[b]; s.iters = W.iters[b]; s.ls = W.ls[b]; s.ls0 = W.ls0[b]; s.lsst = W.lsst[b]; s.cur = W.cur[b];
   s.newstep = W.newstep[b]; s.redo = W.redo[b]; s.force_gn = W.force_gn[b]; s.gn_sticky = W.gn_sticky[b];
   s.curv_fail = W.curv_fail[b]; s.usedc = W.usedc[b]; s.stall = W.stall[b]; s.curv_skip = W.curv_skip[b]; s.curv_back = W.curv_back[b];
+  s.small_steps = W.small_steps[b]; s.mu_hold = W.mu_hold[b];
 }
 __device__ __forceinline__ void inst_store(const Inst &s, const Ws &W, int b) {
   W.mu[b] = s.mu; W.rho[b] = s.rho; W.phi0[b] = s.phi0; W.Dd[b] = s.Dd; W.fcur[b] = s.fcur; W.thcur[b] = s.thcur;
@@ -1464,6 +1475,7 @@ __device__ __forceinline__ void inst_store(const Inst &s, const Ws &W, int b) {
   W.status[b] = s.status; W.iters[b] = s.iters; W.ls[b] = s.ls; W.ls0[b] = s.ls0; W.lsst[b] = s.lsst; W.cur[b] = s.cur;
   W.newstep[b] = s.newstep; W.redo[b] = s.redo; W.force_gn[b] = s.force_gn; W.gn_sticky[b] = s.gn_sticky;
   W.curv_fail[b] = s.curv_fail; W.usedc[b] = s.usedc; W.stall[b] = s.stall; W.curv_skip[b] = s.curv_skip; W.curv_back[b] = s.curv_back;
+  W.small_steps[b] = s.small_steps; W.mu_hold[b] = s.mu_hold;
 }
 
 // whole-horizon sums / maxima of the trial point the last sweep evaluated (+ the merit slope of the step)
@@ -1481,6 +1493,7 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
   int iters = s.iters;
   const bool redo = (!first) && (s.redo != 0);
   int lsst = first ? 0 : s.lsst;
+  double alpha_acc = 1.0;   // length of the step accepted in this pass (barrier restart)
   usec = false;
   if (first) {
     if (r.badf != 0.0) status = -7;  // inverse-barrier row not strictly feasible at the start
@@ -1542,6 +1555,7 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
     // whose steps overshoot every iteration -- the unicycle -- otherwise pay a pass per halving per iteration)
     lsst = ls > kLsGrow ? ls - kLsGrow : 0;
     s.lsst = lsst;
+    alpha_acc = alpha;
     iters++;
   }
   // ---- accept the trial point ------------------------------------------------------
@@ -1567,6 +1581,20 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
         if (sg > 0.8) sg = 0.8;
         mu = sg * avg;
         if (mu < 0.1 * M.tol_comp) mu = 0.1 * M.tol_comp;
+        // barrier restart on stalled steps (oracle: ORC_RS_*): from iteration kRsIt on, kRsN accepted steps in
+        // a row shorter than kRsAlpha while mu < kRsMu -- the iterate crawls along a boundary with the barrier at its
+        // floor -- hold mu at kRsMu, released by the factor kRsDecay per iteration
+        {
+          int ss = (iters - 1 >= kRsIt && alpha_acc < kRsAlpha) ? s.small_steps + 1 : 0;
+          double mh = s.mu_hold;
+          if (ss >= kRsN && mu < kRsMu && !(mh > 0.0)) { mh = kRsMu; ss = 0; }
+          if (mh > 0.0) {
+            if (mu < mh) mu = mh;
+            mh *= kRsDecay;
+            if (mh < 0.1 * M.tol_comp) mh = 0.0;
+          }
+          s.small_steps = ss; s.mu_hold = mh;
+        }
         s.mu = mu;
         if (!(mu < kMuDiverged)) status = -7;
       }
@@ -5626,10 +5654,10 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   W.amin_p = c.take<unsigned long long>(Bp);
   W.amin_d = c.take<unsigned long long>(Bp);
   double **per[] = {&W.mu, &W.rho, &W.phi0, &W.Dd, &W.fcur, &W.thcur, &W.logcur,
-                    &W.res_stat, &W.res_eq, &W.res_ineq, &W.res_comp, &W.obj};
+                    &W.res_stat, &W.res_eq, &W.res_ineq, &W.res_comp, &W.obj, &W.mu_hold};
   for (auto pp : per) *pp = c.take<double>(Bp);
   int **peri[] = {&W.status, &W.iters, &W.ls, &W.cur, &W.newstep, &W.redo, &W.force_gn, &W.gn_sticky, &W.curv_fail, &W.usedc, &W.stall,
-                  &W.ls0, &W.lsst, &W.curv_skip, &W.curv_back};
+                  &W.ls0, &W.lsst, &W.curv_skip, &W.curv_back, &W.small_steps};
   for (auto pp : peri) *pp = c.take<int>(Bp);
   W.active_hist = c.take<int>(max_passes + 8);
   W.act_idx = c.take<int>(Bp);

@@ -1,0 +1,8 @@
+# development aid (round 4): the barrier-restart rule (library: scripts/dev_build.sh 0x25) against the oracle on whole bench input sets, then timing
+mkdir -p gpurun_out
+export RMPC_ALLOW_STALE=1 RMPC_LIB_PATH=$PWD/robot_mpcs_amd/csrc/librmpc_hip_dev.so
+for c in "cfg2 4096 1000" "cfg2 4096 1068" "cfg3 4096 2000" "cfg3 2048 2017" "cfg4 1024 2000"; do
+  echo "== $c"
+  timeout -k 10 300 python tests/tools/dev_vs_oracle.py $c > gpurun_out/r04_vs_one.log 2>&1 || { tail -5 gpurun_out/r04_vs_one.log; exit 1; }
+  tail -1 gpurun_out/r04_vs_one.log | cut -c1-330
+done
