@@ -369,6 +369,39 @@ def test_edge_cases(rt):
     s.close()
 
 
+@pytest.mark.parametrize("name,B,kw", [("cfg2", 96, {}), ("cfg3", 96, {}), ("cfg4", 48, {}), ("wc_boxer_slack", 64, {}),
+                                       ("cfg2", 96, {"RMPC_NO_FUSED": "1"}), ("cfg4", 48, {"RMPC_NO_FUSED": "1"})])
+def test_non_finite_inputs_are_contained(rt, name, B, kw, monkeypatch):
+    """NaN / Inf in the inputs of some instances (start state, one parameter, the initial guess, every parameter): those
+    instances stop at iteration 0 with a negative exit flag on both sides (the reference prints the flag and goes on,
+    mpcPlanner.py:263-264), the launch ends, and EVERY OTHER instance -- also the one that shares a wavefront with a
+    poisoned one -- returns bit for bit what it returns from clean inputs (fused kernels and pass kernels)."""
+    for k, v in kw.items():
+        monkeypatch.setenv(k, v)
+    sc = rt["make_scenario"](name, B=B, seed=21)
+    d = sc.desc
+    N, nx, npar = d["N"], d["nx"], d["npar"]
+    s = rt["Solver"](d, max_batch=B)
+    clean = s.solve(sc.xinit, sc.x0, sc.params)
+    xi, x0, pr = sc.xinit.copy(), sc.x0.copy(), sc.params.copy()
+    xi[3, 0] = np.nan
+    pr.reshape(B, N, npar)[7, 2, 1] = np.inf
+    x0.reshape(B, N, -1)[11, 5, nx:] = np.nan
+    pr.reshape(B, N, npar)[12, :, :] = np.nan
+    bad = np.array([3, 7, 11, 12])
+    gpu = s.solve(xi, x0, pr)
+    again = s.solve(sc.xinit, sc.x0, sc.params)      # the handle carries nothing over from the poisoned launch
+    s.close()
+    cpu = rt["Oracle"](d).solve_batch(xi, x0, pr)
+    good = np.setdiff1d(np.arange(B), bad)
+    assert np.all(gpu["exitflag"][bad] < 0) and np.all(cpu["exitflag"][bad] < 0)
+    assert np.all(gpu["iters"][bad] == 0) and np.all(cpu["iters"][bad] == 0)
+    for k in ("z", "exitflag", "iters", "obj"):
+        assert np.array_equal(gpu[k][good], clean[k][good]), k
+        assert np.array_equal(again[k], clean[k]), k
+    assert np.array_equal(cpu["exitflag"][good], gpu["exitflag"][good])
+
+
 def test_line_search_cap_matches_oracle(rt):
     """ls_max (rmpc_desc.ls_max): instances that exhaust their halvings stop with -8 on both sides."""
     sc = rt["make_scenario"]("cfg3", B=256, seed=12)
