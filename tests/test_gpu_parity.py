@@ -347,6 +347,25 @@ def test_full_size_feasibility_against_oracle_rows(rt, name):
                 assert np.abs(e["xnext"] - r["z"][b, k + 1, : o.nx]).max() <= 2e-6
 
 
+@pytest.mark.parametrize("name,B,chunk", [("cfg2", 32768, 4096), ("cfg3", 16384, 4096), ("cfg4", 8192, 1024)])
+def test_large_batch_equals_its_chunks(rt, name, B, chunk):
+    """Eight times BASELINE's batch in ONE call (the queue behind the grid is 16 to 32 instances deep per half-wavefront)
+    against the same instances solved chunk by chunk through a handle of BASELINE's size: plans, flags, iteration counts
+    and objectives bit for bit -- what an instance returns depends neither on the batch it travels in nor on its place
+    in the queue."""
+    sc = rt["make_scenario"](name, B=B, seed=77)
+    big = rt["Solver"](sc.desc, max_batch=B)
+    r = big.solve(sc.xinit, sc.x0, sc.params)
+    big.close()
+    assert np.all(r["exitflag"] >= 0) and np.isin(r["exitflag"], (1, 2)).mean() > 0.99
+    small = rt["Solver"](sc.desc, max_batch=chunk)
+    for c in range(0, B, chunk):
+        q = small.solve(sc.xinit[c:c + chunk], sc.x0[c:c + chunk], sc.params[c:c + chunk])
+        for k in ("z", "exitflag", "iters", "obj"):
+            assert np.array_equal(q[k], r[k][c:c + chunk]), (k, c)
+    small.close()
+
+
 def test_edge_cases(rt):
     sc = rt["make_scenario"]("cfg1", B=1)
     s = rt["Solver"](sc.desc, max_batch=4)
