@@ -656,6 +656,48 @@ def test_device_entry_is_ordered_with_the_callers_stream(rt):
     s.close()
 
 
+def test_concurrent_handles_return_serial_results(rt):
+    """Six handles (point robot, boxer, arm, a gantry, an arm on the pass kernels' sizes and a row-described model) driven
+    by six host threads on six streams at once, five launches each, twice the chip's wavefronts in flight: every launch
+    returns bit for bit what the same handle returns when it runs alone -- handles share no state on the device."""
+    import threading
+    import torch
+    dev = torch.device("cuda:0")
+    cases = [("cfg2", 4096, 91), ("cfg3", 2048, 92), ("cfg4", 1024, 93), ("chain2", 1024, 94), ("chain8", 256, 95), ("plug_panda", 512, 96)]
+    work = []
+    for name, B, seed in cases:
+        sc = rt["make_scenario"](name, B=B, seed=seed)
+        s = rt["Solver"](sc.desc, max_batch=B)
+        ref = s.solve(sc.xinit, sc.x0, sc.params)
+        N, nv = sc.desc["N"], s.nvar
+        t = dict(x=torch.from_numpy(sc.xinit).to(dev), z0=torch.from_numpy(sc.x0).to(dev), p=torch.from_numpy(sc.params).to(dev),
+                 z=[torch.empty((B, N, nv), dtype=torch.float64, device=dev) for _ in range(5)],
+                 e=[torch.empty(B, dtype=torch.int32, device=dev) for _ in range(5)], i=[torch.empty(B, dtype=torch.int32, device=dev) for _ in range(5)],
+                 k=torch.empty(B, dtype=torch.float64, device=dev), o=torch.empty(B, dtype=torch.float64, device=dev))
+        work.append((s, B, ref, t, torch.cuda.Stream()))
+    torch.cuda.synchronize()
+    errors = []
+
+    def run(w):
+        s, B, ref, t, st = w
+        try:
+            for r in range(5):
+                s.solve_device(B, t["x"], t["z0"], t["p"], t["z"][r], t["e"][r], t["i"][r], t["k"], t["o"], stream=st.cuda_stream)
+        except Exception as ex:      # noqa: BLE001 -- reported by the main thread
+            errors.append(ex)
+
+    th = [threading.Thread(target=run, args=(w,)) for w in work]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for (s, B, ref, t, st), (name, _, _) in zip(work, cases):
+        for r in range(5):
+            assert np.array_equal(t["z"][r].cpu().numpy(), ref["z"]), (name, r)
+            assert np.array_equal(t["e"][r].cpu().numpy(), ref["exitflag"]) and np.array_equal(t["i"][r].cpu().numpy(), ref["iters"]), (name, r)
+        s.close()
+
+
 @pytest.mark.parametrize("name,B,budget", [("cfg4", 96, 13), ("cfg2", 128, 14), ("cfg3", 64, 24)])
 def test_pass_budget_cuts_only_the_unfinished(rt, name, B, budget):
     """rmpc_set_pass_budget: instances that finish within the budget return exactly what they return without one;
