@@ -79,6 +79,32 @@ def test_warm_start_is_per_instance_and_forgets_on_mode_change(rt):
     s.close()
 
 
+@pytest.mark.parametrize("name,B", [("cfg2", 64), ("cfg3", 64), ("cfg4", 32)])
+def test_warm_start_recovers_after_a_poisoned_solve(rt, name, B):
+    """A warm-started handle whose instance 4 gets a NaN start state for ONE control step: that solve fails (flag < 0), its
+    multipliers are not kept, and the next solve from clean inputs converges again to the cold solve's objective; every other
+    instance goes through the three steps bit for bit like a twin handle that never saw the NaN."""
+    sc = rt["make_scenario"](name, B=B, seed=15)
+    a = rt["Solver"](sc.desc, max_batch=B); a.set_warm_start(True)
+    b = rt["Solver"](sc.desc, max_batch=B); b.set_warm_start(True)
+    cold = a.solve(sc.xinit, sc.x0, sc.params)
+    b.solve(sc.xinit, sc.x0, sc.params)
+    xi = sc.xinit.copy(); xi[4, 1] = np.nan
+    bad = a.solve(xi, cold["z"], sc.params)
+    twin2 = b.solve(sc.xinit, cold["z"], sc.params)
+    assert bad["exitflag"][4] < 0 and bad["iters"][4] == 0
+    others = np.arange(B) != 4
+    for k in ("z", "exitflag", "iters"):
+        assert np.array_equal(bad[k][others], twin2[k][others]), k
+    rec = a.solve(sc.xinit, cold["z"], sc.params)
+    twin3 = b.solve(sc.xinit, cold["z"], sc.params)
+    a.close(); b.close()
+    assert rec["exitflag"][4] >= 1
+    assert abs(rec["obj"][4] - cold["obj"][4]) <= 1e-5 * max(1.0, abs(cold["obj"][4]))
+    for k in ("z", "exitflag", "iters"):
+        assert np.array_equal(rec[k][others], twin3[k][others]), k
+
+
 def test_mixed_fleet_shard_closed_loop(rt):
     """BASELINE configs[4] ("mixed fleet ... 100 Hz real-time loop"), one GPU's shard in the SURVEY 8(e) proportions
     (4 : 3 : 1, scaled down to 1024 instances so that the oracle can follow a sample), device-resident loop:
