@@ -307,6 +307,8 @@ static int dd_curv(const orc_desc *d) {
 static int backoff_model(const orc_desc *d) {
   return dd_curv(d) || (d->robot == ORC_ROBOT_CHAIN && d->ns == 0 && d->n <= 3);
 }
+/* models whose curvature terms are scaled down before they are given up for an iteration (ORC_CS_*) */
+static int cscale_model(const orc_desc *d) { return d->robot == ORC_ROBOT_CHAIN && d->ns == 0 && d->n <= 3; }
 /* models whose distance rows and goal cost carry second derivatives of the kinematics */
 static int with_fk_curv(const orc_desc *d) { return arm_curv(d) || dd_curv(d); }
 
@@ -683,6 +685,13 @@ int orc_eval_stage(const orc_desc *d, const double *z, const double *p,
 #define ORC_RS_ALPHA 0.2
 #define ORC_RS_MU 1e-3
 #define ORC_RS_DECAY 0.3
+/* scaled curvature (round 4, the small holonomic chains): a failed factorisation with the exact constraint curvature is
+ * retried with the curvature terms scaled by theta = 1/2, 1/4 (Q = Gauss-Newton blocks + theta * curvature: the blocks
+ * are positive definite at theta = 0) before the iteration falls back to Gauss-Newton; the scale that worked is kept
+ * for the next iteration and doubled again after ORC_CS_CLEAN accepted curvature steps in a row that needed no retry
+ *  */
+#define ORC_CS_MIN 0.3
+#define ORC_CS_CLEAN 3
 #define ORC_TRACE_W 8
 
 typedef struct {
@@ -1071,6 +1080,9 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
   double mu = d->mu0, rho = 0.0;
   int small_steps = 0;   /* barrier restart: accepted short steps in a row, the level mu is held at */
   double mu_hold = 0.0;
+  double theta_mem = 1.0;   /* scaled curvature: the scale the next curvature step starts from, clean successes in a row */
+  int theta_clean = 0;
+  const int cscale = cscale_model(d);
   int exitflag = 0, it = 0;
   const int curv_ok = model_uses_curvature(d);
   int gn_sticky = 0, curv_fail = 0, stall = 0;
@@ -1174,6 +1186,8 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
     if (use_curv && backoff_model(d) && curv_skip > 0) { curv_skip--; use_curv = 0; }
     double alpha = 0.0, ad = 1.0;
     int ls = 0, accepted = 0, fatal = 0;
+    double theta_c = cscale ? theta_mem : 1.0;
+    int theta_retry = 0;
     for (;;) {
       for (int k = 0; k < N; k++) {
         const double *Jg = w->Jg + (size_t)k * MRM * nv;
@@ -1195,17 +1209,18 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
             const double *Cm = w->Cc + ((size_t)k * ORC_NH_MAX + i) * 64;
             double wgt = lv + w->cw[(size_t)k * ORC_NH_MAX + i];
             for (int a2 = 0; a2 < d->n; a2++)
-              for (int b2 = 0; b2 < d->n; b2++) Q[a2 * nv + b2] -= wgt * Cm[a2 * d->n + b2];
+              for (int b2 = 0; b2 < d->n; b2++) Q[a2 * nv + b2] -= theta_c * (wgt * Cm[a2 * d->n + b2]);
           }
         }
         if (use_curv && d->has_goal) {
           const double *G = w->Gc + (size_t)k * 64;
           for (int a2 = 0; a2 < d->n; a2++)
-            for (int b2 = 0; b2 < d->n; b2++) Q[a2 * nv + b2] += G[a2 * d->n + b2];
+            for (int b2 = 0; b2 < d->n; b2++) Q[a2 * nv + b2] += theta_c * G[a2 * d->n + b2];
         }
         if (use_curv && dd_curv(d) && k < N - 1) dd_dyn_curv(d, w->z + (size_t)k * nv, w->nu + (size_t)(k + 1) * nx, Q);
       }
       if (riccati(w) != 0) {
+        if (use_curv && cscale && theta_c > ORC_CS_MIN) { theta_c *= 0.5; theta_retry = 1; tl_passes++; continue; }
         if (use_curv) {
           use_curv = 0;
           tl_passes++;
@@ -1266,6 +1281,12 @@ static int solve_impl(const orc_desc *d, const double *xinit, const double *x0, 
         continue;
       }
       if (accepted && use_curv) { curv_fail = 0; curv_back = 0; }
+      if (cscale) {
+        if (accepted && use_curv) {
+          if (theta_retry) { theta_mem = theta_c; theta_clean = 0; }
+          else if (++theta_clean >= ORC_CS_CLEAN) { theta_mem = theta_c < 0.75 ? 2.0 * theta_c : 1.0; theta_clean = 0; }
+        } else if (accepted && theta_retry) { theta_mem = theta_c; theta_clean = 0; }
+      }
       /* the arms: a Gauss-Newton step accepted at full length releases the latch (the failures that set it
        * belong to the first iterations of a warm start, where the fraction to the boundary cuts the steps) */
       if (accepted && !use_curv && ls == 0 && arm_curv(d)) { gn_sticky = 0; curv_fail = 0; }

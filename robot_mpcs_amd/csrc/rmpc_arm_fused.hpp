@@ -844,7 +844,7 @@ __device__ __noinline__ bool arm_recursion_call(const int N, const double dt, co
                                                 ldouble *const lstep, ldouble *const limg, const int lcap) {
   StepOut<ldouble> so;
   so.dz = lstep; so.nunew = lstep + C::NV; so.SS = 1; so.KS = ArmLds<C>::SW;
-  return riccati_recursion<C, 64, false, gdouble, false, ldouble>(N, dt, mu, usec, lane, work, grec, kpb, kps, so, nullptr, limg, lcap);
+  return riccati_recursion<C, 64, false, gdouble, false, ldouble>(N, dt, mu, usec ? 1.0 : 0.0, lane, work, grec, kpb, kps, so, nullptr, limg, lcap);
 }
 
 template <class C, int P>

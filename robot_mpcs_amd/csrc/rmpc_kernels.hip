@@ -90,6 +90,8 @@ constexpr int kLsCurv = 2;        // trials granted to a step computed with cons
 constexpr int kCurvFailMax = 2;   // consecutive curvature-step failures before Gauss-Newton is latched
 constexpr int kCurvBackMax = 16;  // (diff-drive) longest run of iterations a failed curvature step switches the terms off
 constexpr int kGroupedMin = 512;    // list length from which the grouped Riccati blocks are used
+constexpr double kCsMin = 0.3;    // scaled curvature (oracle: ORC_CS_MIN, ORC_CS_CLEAN)
+constexpr int kCsClean = 3;
 constexpr double kAccFeas = 1e-6; // acceptable termination: feasibility / complementarity level
 constexpr int kDenseDiv = 8;      // identity list while more than B / kDenseDiv instances iterate; below: compacted list,
                                   // and the survivors move to the compact workspace at the host's next look
@@ -129,6 +131,8 @@ struct Ws {
   int *redo, *force_gn, *gn_sticky, *curv_fail, *usedc, *stall;
   int *curv_skip, *curv_back;     // (diff-drive) curvature steps still to be skipped / length of the last skip (back-off)
   int *small_steps;               // barrier restart: accepted short steps in a row
+  double *theta_mem, *theta_c;    // scaled curvature (Cfg::CSCALE): the scale the next curvature step starts from / of this iteration
+  int *theta_clean, *theta_retry; // ... accepted curvature steps in a row without a retry / this iteration has retried
   int *ls0, *lsst;                // halvings the current line search started from / the next one starts from
   int *active_hist;               // [max_passes] instances still iterating after each pass
   int *act_idx, *n_act;           // compacted list of the instances still iterating, its length
@@ -201,6 +205,7 @@ __global__ __launch_bounds__(256) void k_init(Ws W, const double *__restrict__ x
   W.redo[b] = 0; W.force_gn[b] = 0; W.gn_sticky[b] = 0; W.curv_fail[b] = 0; W.usedc[b] = 0; W.stall[b] = 0;
   W.curv_skip[b] = 0; W.curv_back[b] = 0;
   W.small_steps[b] = 0; W.mu_hold[b] = 0.0;
+  W.theta_mem[b] = 1.0; W.theta_c[b] = 1.0; W.theta_clean[b] = 0; W.theta_retry[b] = 0;
   W.ls0[b] = 0; W.lsst[b] = 0;
   W.mu[b] = warm ? warm_mu(W.wmu[b], mu0) : mu0;
   W.rho[b] = 0.0;
@@ -423,6 +428,7 @@ __global__ __launch_bounds__(64) void k_migrate(const Ws S, const Ws D, int n, i
     D.curv_fail[li] = S.curv_fail[b]; D.usedc[li] = S.usedc[b]; D.stall[li] = S.stall[b];
     D.curv_skip[li] = S.curv_skip[b]; D.curv_back[li] = S.curv_back[b];
     D.small_steps[li] = S.small_steps[b]; D.mu_hold[li] = S.mu_hold[b];
+    D.theta_mem[li] = S.theta_mem[b]; D.theta_c[li] = S.theta_c[b]; D.theta_clean[li] = S.theta_clean[b]; D.theta_retry[li] = S.theta_retry[b];
     D.ls0[li] = S.ls0[b]; D.lsst[li] = S.lsst[b];
     D.cur[li] = 0;
     D.orig[li] = b;
@@ -1448,6 +1454,8 @@ struct Inst {
   double mu_hold;          // barrier restart: the level mu is held at (0: none)
   int status, iters, ls, ls0, lsst, cur, newstep, redo, force_gn, gn_sticky, curv_fail, usedc, stall, curv_skip, curv_back;
   int small_steps;         // barrier restart: accepted short steps in a row
+  double theta_mem, theta_c;      // scaled curvature: the scale the next curvature step starts from / of this iteration
+  int theta_clean, theta_retry;   // accepted curvature steps in a row without a retry / this iteration has retried
 };
 __device__ __forceinline__ void inst_init(Inst &s, double mu0) {
   s.mu = mu0; s.rho = 0.0; s.phi0 = 0.0; s.Dd = 0.0; s.fcur = 0.0; s.thcur = 0.0; s.logcur = 0.0;
@@ -1456,6 +1464,7 @@ __device__ __forceinline__ void inst_init(Inst &s, double mu0) {
   s.status = ST_ACTIVE; s.iters = 0; s.ls = 0; s.ls0 = 0; s.lsst = 0; s.cur = 0; s.newstep = 0; s.redo = 0;
   s.force_gn = 0; s.gn_sticky = 0; s.curv_fail = 0; s.usedc = 0; s.stall = 0; s.curv_skip = 0; s.curv_back = 0;
   s.small_steps = 0; s.mu_hold = 0.0;
+  s.theta_mem = 1.0; s.theta_c = 1.0; s.theta_clean = 0; s.theta_retry = 0;
 }
 __device__ __forceinline__ void inst_load(Inst &s, const Ws &W, int b) {
   s.mu = W.mu[b]; s.rho = W.rho[b]; s.phi0 = W.phi0[b]; s.Dd = W.Dd[b]; s.fcur = W.fcur[b]; s.thcur = W.thcur[b];
@@ -1466,6 +1475,7 @@ __device__ __forceinline__ void inst_load(Inst &s, const Ws &W, int b) {
   s.newstep = W.newstep[b]; s.redo = W.redo[b]; s.force_gn = W.force_gn[b]; s.gn_sticky = W.gn_sticky[b];
   s.curv_fail = W.curv_fail[b]; s.usedc = W.usedc[b]; s.stall = W.stall[b]; s.curv_skip = W.curv_skip[b]; s.curv_back = W.curv_back[b];
   s.small_steps = W.small_steps[b]; s.mu_hold = W.mu_hold[b];
+  s.theta_mem = W.theta_mem[b]; s.theta_c = W.theta_c[b]; s.theta_clean = W.theta_clean[b]; s.theta_retry = W.theta_retry[b];
 }
 __device__ __forceinline__ void inst_store(const Inst &s, const Ws &W, int b) {
   W.mu[b] = s.mu; W.rho[b] = s.rho; W.phi0[b] = s.phi0; W.Dd[b] = s.Dd; W.fcur[b] = s.fcur; W.thcur[b] = s.thcur;
@@ -1476,6 +1486,7 @@ __device__ __forceinline__ void inst_store(const Inst &s, const Ws &W, int b) {
   W.newstep[b] = s.newstep; W.redo[b] = s.redo; W.force_gn[b] = s.force_gn; W.gn_sticky[b] = s.gn_sticky;
   W.curv_fail[b] = s.curv_fail; W.usedc[b] = s.usedc; W.stall[b] = s.stall; W.curv_skip[b] = s.curv_skip; W.curv_back[b] = s.curv_back;
   W.small_steps[b] = s.small_steps; W.mu_hold[b] = s.mu_hold;
+  W.theta_mem[b] = s.theta_mem; W.theta_c[b] = s.theta_c; W.theta_clean[b] = s.theta_clean; W.theta_retry[b] = s.theta_retry;
 }
 
 // whole-horizon sums / maxima of the trial point the last sweep evaluated (+ the merit slope of the step)
@@ -1546,6 +1557,14 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
       return false;  // next sweep retries with alpha / 2
     }
     if (usedc) { s.curv_fail = 0; s.curv_back = 0; }
+    if constexpr (C::CSCALE) {
+      // scaled curvature: the scale that needed a retry is kept, kCsClean accepted curvature steps in a row without a
+      // retry double it again; an iteration whose retries all failed (Gauss-Newton step accepted) keeps the last scale
+      if (usedc) {
+        if (s.theta_retry) { s.theta_mem = s.theta_c; s.theta_clean = 0; }
+        else if (++s.theta_clean >= kCsClean) { s.theta_mem = s.theta_c < 0.75 ? 2.0 * s.theta_c : 1.0; s.theta_clean = 0; }
+      } else if (s.theta_retry) { s.theta_mem = s.theta_c; s.theta_clean = 0; }
+    }
     // the arms: a Gauss-Newton step accepted at full length releases the latch (the failures that set it belong to
     // the first iterations of a warm start, where the fraction to the boundary cuts the steps)
     if constexpr (C::FKCURV) {
@@ -1627,6 +1646,9 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
     if (usec && s.curv_skip > 0) { s.curv_skip--; usec = false; }
   }
   s.force_gn = 0;
+  if constexpr (C::CSCALE) {
+    if (!redo) { s.theta_c = s.theta_mem; s.theta_retry = 0; }   // (a null pass belongs to the iteration that asked for it)
+  }
   // a step with the exact curvature is tried at full length first
   const int lsb = usec ? 0 : lsst;
   s.ls = lsb;
@@ -1634,9 +1656,15 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
   return true;
 }
 // after the recursion: a failed factorisation either falls back to Gauss-Newton (null pass) or stops the instance
-__device__ __forceinline__ void inst_after_recursion(Inst &s, const bool chol_ok, const bool usec, const bool backoff = false) {
+__device__ __forceinline__ void inst_after_recursion(Inst &s, const bool chol_ok, const bool usec, const bool backoff = false,
+                                                     const bool cscale = false) {
   if (!chol_ok) {
     if (usec) {
+      if (cscale && s.theta_c > kCsMin) {
+        // scaled curvature: the same iteration again (null pass next) with the curvature terms at half their weight
+        s.theta_c *= 0.5; s.theta_retry = 1; s.redo = 1; s.usedc = 0;
+        return;
+      }
       if (backoff) {   // (diff-drive: see inst_decide)
         s.curv_back = s.curv_back ? (s.curv_back < kCurvBackMax ? 2 * s.curv_back : kCurvBackMax) : 1;
         s.curv_skip = s.curv_back;
@@ -1742,7 +1770,7 @@ struct FusedSlots {
 };
 
 template <class C, int LPI, bool SLOTS = false, class RP = gdouble, bool OWNER = false, class SP = RP>
-__device__ __forceinline__ bool riccati_recursion(const int N, const double dt, const double mu, const bool usec, const int lane,
+__device__ __forceinline__ bool riccati_recursion(const int N, const double dt, const double mu, const double cw, const int lane,
                                                   ldouble *const img, const RP *const rb, gdouble *const kpb,
                                                   const int kps, const StepOut<SP> so, ldouble *const slots = nullptr,
                                                   ldouble *const limg = nullptr, const int lcap_rt = -1) {
@@ -1753,7 +1781,7 @@ __device__ __forceinline__ bool riccati_recursion(const int N, const double dt, 
   constexpr int GS = FusedSlots<C>::GS;
   constexpr int NQ = C::NQ, NX = C::NX, NS = C::NS, NV = C::NV, NW = C::NW;
   constexpr bool DD = (C::ROBOT == RMPC_ROBOT_DIFFDRIVE);
-  const double cwt = usec ? 1.0 : 0.0;  // Cqq is zero-filled when the model does not use it
+  const double cwt = cw;  // weight of the curvature terms (0: Gauss-Newton blocks, 1: exact, 1/2, 1/4: Cfg::CSCALE); Cqq is zero-filled when the model does not use it
   // ---- LDS images -------------------------------------------------------------------------
   // img = [K | kff | P (upper triangle) | p | rc]: what the forward pass needs of a stage, contiguous in
   // LDS so that it leaves for (and returns from) the instance's gain record KP in one request
@@ -3416,7 +3444,8 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
   static_assert(IMGW == 0 || IPB * IPW == 1, "image slots: one instance per block");
   StepOut<gdouble> so;
   so.dz = (gdouble *)(W.dz + b); so.nunew = (gdouble *)(W.nunew + b); so.SS = (size_t)N * W.Bp; so.KS = (size_t)W.Bp;
-  const bool chol_ok = riccati_recursion<C, LPI, false, gdouble>(M.N, M.dt, mu, usec, lane, (ldouble *)lds[wv],
+  const double cw = usec ? (C::CSCALE ? s.theta_c : 1.0) : 0.0;
+  const bool chol_ok = riccati_recursion<C, LPI, false, gdouble>(M.N, M.dt, mu, cw, lane, (ldouble *)lds[wv],
                                                                  (const gdouble *)(W.R + (size_t)b * N * C::RS),
                                                                  (gdouble *)(W.KP + (size_t)b * N * W.kps), W.kps, so,
                                                                  nullptr, (ldouble *)limg);
@@ -3424,10 +3453,14 @@ __global__ __launch_bounds__(64 * IPB, C::RIC_WPE) void k_riccati(const DevModel
     // = inst_after_recursion on the stored words
     if (!chol_ok) {
       if (usec) {
-        W.redo[b] = 1; W.force_gn[b] = 1; W.usedc[b] = 0;
-        if constexpr (C::BACKOFF) {
-          const int cb = s.curv_back ? (s.curv_back < kCurvBackMax ? 2 * s.curv_back : kCurvBackMax) : 1;
-          W.curv_back[b] = cb; W.curv_skip[b] = cb;
+        if (C::CSCALE && s.theta_c > kCsMin) {   // scaled curvature: the iteration again at half the weight
+          W.theta_c[b] = 0.5 * s.theta_c; W.theta_retry[b] = 1; W.redo[b] = 1; W.usedc[b] = 0;
+        } else {
+          W.redo[b] = 1; W.force_gn[b] = 1; W.usedc[b] = 0;
+          if constexpr (C::BACKOFF) {
+            const int cb = s.curv_back ? (s.curv_back < kCurvBackMax ? 2 * s.curv_back : kCurvBackMax) : 1;
+            W.curv_back[b] = cb; W.curv_skip[b] = cb;
+          }
         }
       }
       else W.status[b] = -5;
@@ -3483,7 +3516,7 @@ __global__ __launch_bounds__(64) void k_riccati_lane(const DevModel M, const Ws 
   const bool recurse = inst_decide<C>(M, s, r, first != 0, usec);
   inst_store(s, W, b);
   if (!recurse) return;
-  const double mu = s.mu, cwt = usec ? 1.0 : 0.0;
+  const double mu = s.mu, cwt = usec ? (C::CSCALE ? s.theta_c : 1.0) : 0.0;
   const double h = M.dt, h2 = 0.5 * M.dt * M.dt;
   constexpr int NP2 = NX * (NX + 1) / 2;
   constexpr int OFF_KFF = NW * NX, OFF_PT = NW * NX + NW, OFF_P = OFF_PT + NP2, OFF_RC = OFF_P + NX;
@@ -3683,10 +3716,14 @@ __global__ __launch_bounds__(64) void k_riccati_lane(const DevModel M, const Ws 
   // = inst_after_recursion on the stored words
   if (!chol_ok) {
     if (usec) {
-      W.redo[b] = 1; W.force_gn[b] = 1; W.usedc[b] = 0;
-      if constexpr (C::BACKOFF) {
-        const int cb = s.curv_back ? (s.curv_back < kCurvBackMax ? 2 * s.curv_back : kCurvBackMax) : 1;
-        W.curv_back[b] = cb; W.curv_skip[b] = cb;
+      if (C::CSCALE && s.theta_c > kCsMin) {   // scaled curvature: the iteration again at half the weight
+        W.theta_c[b] = 0.5 * s.theta_c; W.theta_retry[b] = 1; W.redo[b] = 1; W.usedc[b] = 0;
+      } else {
+        W.redo[b] = 1; W.force_gn[b] = 1; W.usedc[b] = 0;
+        if constexpr (C::BACKOFF) {
+          const int cb = s.curv_back ? (s.curv_back < kCurvBackMax ? 2 * s.curv_back : kCurvBackMax) : 1;
+          W.curv_back[b] = cb; W.curv_skip[b] = cb;
+        }
       }
     }
     else W.status[b] = -5;
@@ -3921,15 +3958,15 @@ struct FusedWs {
 #define RMPC_PHASE __noinline__ RMPC_ONE_WAVE
 #endif
 template <class C>
-__device__ RMPC_PHASE bool fused_recursion_lds(const int N, const double dt, const double mu, const bool usec, const int lane,
+__device__ RMPC_PHASE bool fused_recursion_lds(const int N, const double dt, const double mu, const double cw, const int lane,
                                                ldouble *const work, ldouble *const slots, const StepOut<ldouble> so) {
-  return riccati_recursion<C, kFusedStages, true, ldouble>(N, dt, mu, usec, lane, work, slots, nullptr, 0, so, slots);
+  return riccati_recursion<C, kFusedStages, true, ldouble>(N, dt, mu, cw, lane, work, slots, nullptr, 0, so, slots);
 }
 template <class C>
-__device__ RMPC_PHASE bool fused_recursion_mem(const int N, const double dt, const double mu, const bool usec, const int lane,
+__device__ RMPC_PHASE bool fused_recursion_mem(const int N, const double dt, const double mu, const double cw, const int lane,
                                                ldouble *const work, const gdouble *const grec, gdouble *const kpb,
                                                const int kps, const StepOut<gdouble> so) {
-  return riccati_recursion<C, kFusedStages, false, gdouble, true>(N, dt, mu, usec, lane, work, grec, kpb, kps, so);
+  return riccati_recursion<C, kFusedStages, false, gdouble, true>(N, dt, mu, cw, lane, work, grec, kpb, kps, so);
 }
 
 // Bases of an instance's block in every array of the fused workspace.  They are recomputed from the instance index
@@ -4441,6 +4478,7 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1), di
     STAMP_B(st_dec);
     park();
     const double mu_r = s.mu;
+    const double cw_r = usec ? (C::CSCALE ? s.theta_c : 1.0) : 0.0;   // weight of the curvature terms in this recursion
     bool rec_ok = true;
     double ap = 1.0, ad = 1.0, gp = 0.0;
     if (recurse) {
@@ -4448,18 +4486,18 @@ __global__ __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1), di
       if constexpr (REC_LDS) {
         StepOut<ldouble> so;
         so.dz = slots + DZ_OFF; so.nunew = slots + DZ_OFF + NV; so.SS = 1; so.KS = GS;
-        ok = fused_recursion_lds<C>(M.N, M.dt, mu_r, usec, k, work, slots, so);
+        ok = fused_recursion_lds<C>(M.N, M.dt, mu_r, cw_r, k, work, slots, so);
       } else {
         const FusedPtrs Pr = fused_ptrs(F, b);
         StepOut<gdouble> so;
         so.dz = Pr.pdz; so.nunew = Pr.pnn; so.SS = S; so.KS = 1;
-        ok = fused_recursion_mem<C>(M.N, M.dt, mu_r, usec, k, work, (gdouble *)F.R + b * (size_t)N * C::RS,
+        ok = fused_recursion_mem<C>(M.N, M.dt, mu_r, cw_r, k, work, (gdouble *)F.R + b * (size_t)N * C::RS,
                                     (gdouble *)F.KP + b * (size_t)N * F.kps, F.kps, so);
       }
       rec_ok = ok;
     }
     unpark();
-    if (recurse) inst_after_recursion(s, rec_ok, usec, C::BACKOFF);
+    if (recurse) inst_after_recursion(s, rec_ok, usec, C::BACKOFF, C::CSCALE);
     GSYNC();   // dz, nunew
     STAMP_B(st_ric);
     // ---- step lengths of the new step -----------------------------------------------------------------
@@ -5654,10 +5692,10 @@ static size_t carve(const DevModel &M, int Bp, int max_passes, void *base, Ws &W
   W.amin_p = c.take<unsigned long long>(Bp);
   W.amin_d = c.take<unsigned long long>(Bp);
   double **per[] = {&W.mu, &W.rho, &W.phi0, &W.Dd, &W.fcur, &W.thcur, &W.logcur,
-                    &W.res_stat, &W.res_eq, &W.res_ineq, &W.res_comp, &W.obj, &W.mu_hold};
+                    &W.res_stat, &W.res_eq, &W.res_ineq, &W.res_comp, &W.obj, &W.mu_hold, &W.theta_mem, &W.theta_c};
   for (auto pp : per) *pp = c.take<double>(Bp);
   int **peri[] = {&W.status, &W.iters, &W.ls, &W.cur, &W.newstep, &W.redo, &W.force_gn, &W.gn_sticky, &W.curv_fail, &W.usedc, &W.stall,
-                  &W.ls0, &W.lsst, &W.curv_skip, &W.curv_back, &W.small_steps};
+                  &W.ls0, &W.lsst, &W.curv_skip, &W.curv_back, &W.small_steps, &W.theta_clean, &W.theta_retry};
   for (auto pp : peri) *pp = c.take<int>(Bp);
   W.active_hist = c.take<int>(max_passes + 8);
   W.act_idx = c.take<int>(Bp);

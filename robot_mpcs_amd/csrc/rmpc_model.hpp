@@ -237,6 +237,9 @@ struct Cfg {
   // a failed curvature step switches the terms off for 1, 2, 4 .. 16 iterations (back-off) instead of latching them
   // off: the unicycle and the small chains; the arms keep the latch with its release rule (oracle: backoff_model)
   static constexpr bool BACKOFF = DDCURV || (CURV && !FKCURV);
+  // scaled curvature (the small chains; oracle: cscale_model, ORC_CS_*): a failed factorisation with the exact curvature is
+  // retried with the curvature terms at 1/2, 1/4 of their weight before the iteration falls back to Gauss-Newton
+  static constexpr bool CSCALE = CURV && !FKCURV;
   static constexpr int ND = 11;   // (th,om) (th,u1) (om,om) (om,u1) (u1,u1) | (th,v) (th,u0) (om,v) (om,u0) (u1,v) (u1,u0)
   // instances (wavefronts) per block of the grouped Riccati kernel.  Small blocks: with the instance-major
   // records neighbouring instances no longer share cache lines, a 4-wavefront block fits beside a k_sweep
