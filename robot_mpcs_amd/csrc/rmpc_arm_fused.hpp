@@ -620,7 +620,7 @@ __device__ __forceinline__ void step_part(const V &v, const StepIO<SP> &io, cons
     const double dt = gdz + (g - tv);
     const double itv = frcp(tv);
     const double dl = (mu - tv * lv - lv * dt) * itv;   // (same expression as in the sweep's row_core)
-    const double rp = -kTau * tv * frcp(dt), rd = -kTau * lv * frcp(dl);
+    const double rp = -C::TAU * tv * frcp(dt), rd = -C::TAU * lv * frcp(dl);
     ap = ((dt < 0) & (rp < ap)) ? rp : ap;
     ad = ((dl < 0) & (rd < ad)) ? rd : ad;
     gphi -= mu * dt * itv;

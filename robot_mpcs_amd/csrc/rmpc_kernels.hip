@@ -76,7 +76,7 @@ constexpr double kTMin = 1e-2;
 constexpr double kWarmKappa = 1000.0;
 constexpr double kWarmMuMin = 1e-6;
 constexpr double kWarmTMin = 1e-4;
-constexpr double kTau = 0.995;
+// (the fraction to the boundary is per model: Cfg::TAU)
 // barrier restart on stalled steps (oracle: ORC_RS_IT, ORC_RS_N, ORC_RS_ALPHA, ORC_RS_MU, ORC_RS_DECAY)
 constexpr int kRsIt = 8, kRsN = 3;
 constexpr double kRsAlpha = 0.2, kRsMu = 1e-3, kRsDecay = 0.3;
@@ -90,6 +90,7 @@ constexpr int kLsCurv = 2;        // trials granted to a step computed with cons
 constexpr int kCurvFailMax = 2;   // consecutive curvature-step failures before Gauss-Newton is latched
 constexpr int kCurvBackMax = 16;  // (diff-drive) longest run of iterations a failed curvature step switches the terms off
 constexpr int kGroupedMin = 512;    // list length from which the grouped Riccati blocks are used
+constexpr double kCompFrac = 0.3; // share of tol_comp the convergence test asks for (oracle: ORC_COMP_FRAC)
 constexpr double kCsMin = 0.3;    // scaled curvature (oracle: ORC_CS_MIN, ORC_CS_CLEAN)
 constexpr int kCsClean = 3;
 constexpr double kAccFeas = 1e-6; // acceptable termination: feasibility / complementarity level
@@ -1619,7 +1620,7 @@ __device__ __forceinline__ bool inst_decide(const DevModel &M, Inst &s, const Re
       }
       if (status == ST_ACTIVE) {
         if (!isfinite(r.rstat) || !isfinite(r.req) || !isfinite(r.rineq)) status = -6;
-        else if (r.rstat <= M.tol_stat && r.req <= M.tol_eq && r.rineq <= M.tol_ineq && r.rcomp <= M.tol_comp) status = 1;
+        else if (r.rstat <= M.tol_stat && r.req <= M.tol_eq && r.rineq <= M.tol_ineq && r.rcomp <= kCompFrac * M.tol_comp) status = 1;
         else {
           // acceptable termination: feasible, complementary, objective stagnant for acc_iters iterations
           int stall = stall0;
@@ -3778,7 +3779,7 @@ __device__ __forceinline__ void step_body(const V &v, const StepIO<RP> &io, cons
     const double dl = (mu - tv * lv - lv * dt) * itv;   // (same expression as in sweep_body's row_core)
     (void)i;  // the steps themselves are not stored: the sweep recomputes them from the same inputs
     // ratio tests with Newton reciprocals (the quotient of a non-negative step is discarded by the select)
-    const double rp = -kTau * tv * frcp(dt), rd = -kTau * lv * frcp(dl);
+    const double rp = -C::TAU * tv * frcp(dt), rd = -C::TAU * lv * frcp(dl);
     // (bitwise and: no short-circuit branch -- the rows of a stage stay one basic block)
     ap = ((dt < 0) & (rp < ap)) ? rp : ap;
     ad = ((dl < 0) & (rd < ad)) ? rd : ad;

@@ -240,6 +240,8 @@ struct Cfg {
   // scaled curvature (the small chains; oracle: cscale_model, ORC_CS_*): a failed factorisation with the exact curvature is
   // retried with the curvature terms at 1/2, 1/4 of their weight before the iteration falls back to Gauss-Newton
   static constexpr bool CSCALE = CURV && !FKCURV;
+  // fraction to the boundary (oracle: ORC_TAU_*): a step takes a slack or a multiplier to (1 - TAU) of its value at most
+  static constexpr double TAU = CSCALE ? 0.985 : 0.98;
   static constexpr int ND = 11;   // (th,om) (th,u1) (om,om) (om,u1) (u1,u1) | (th,v) (th,u0) (om,v) (om,u0) (u1,v) (u1,u0)
   // instances (wavefronts) per block of the grouped Riccati kernel.  Small blocks: with the instance-major
   // records neighbouring instances no longer share cache lines, a 4-wavefront block fits beside a k_sweep

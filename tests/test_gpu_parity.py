@@ -120,7 +120,10 @@ def test_lane_per_instance_recursion_matches_oracle(rt, name, B, seed, monkeypat
     _check_plan(gpu, cpu, sc.desc["nx"] + sc.desc["ns"])
 
 
-@pytest.mark.parametrize("name,B,seed", [("cfg2", 300, 61), ("wc_point", 200, 62), ("chain2", 200, 63), ("cfg3", 200, 64)])
+# (cfg3: seed 66, not 64 -- instance 14 of seed 64 is one of the rare boxers whose iteration is sensitive to rounding: library and
+#  oracle agree to 4e-13 after 10 iterations, 3e-8 after 20, 6e-5 after 30, and part ways in a crawl that one of them leaves after
+#  109 iterations and the other not within 200; the full-size sweep, profiles/r04_parity_sweep.txt, counts such instances)
+@pytest.mark.parametrize("name,B,seed", [("cfg2", 300, 61), ("wc_point", 200, 62), ("chain2", 200, 63), ("cfg3", 200, 66)])
 def test_queue_and_cold_order_on_a_tiny_grid(rt, name, B, seed, monkeypatch):
     """RMPC_FUSED_GRID=4: eight half-wavefronts drain a queue of hundreds of instances, and a cold launch of the
     chains orders that queue by k_difficulty -- the refill, the per-instance pass counters, the mixed first / later
